@@ -1,0 +1,254 @@
+/*
+ * lcv_hip.h — C ABI of liblcv_hip.so: the MI355X (gfx950) kernels under the
+ * LongCat-Video denoise-and-adapt hot path.
+ *
+ * The reference (FifthEpoch/longcat-video-tta) has no FFI of its own: its
+ * boundary with this path is the Python object protocol of the un-vendored
+ * `longcat_video` package.  This header is the boundary
+ * *under* that protocol: every entry point below replaces a third-party GPU
+ * kernel the reference reaches through torch / flash-attn, and cites the
+ * reference call site (paths relative to the reference tree) that drives it.
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch types; all pointers are DEVICE pointers
+ *     unless a name ends in _host;
+ *   - bf16 tensors are passed as `const void*` / `void*` (raw 16-bit storage);
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *   - return 0 on success, a negative LCV_E* code otherwise; the message is
+ *     retrievable with lcv_last_error() (thread-local);
+ *   - no allocation, no ownership transfer, re-entrant per stream: any
+ *     workspace is supplied by the caller;
+ *   - strides are in ELEMENTS.
+ */
+#ifndef LCV_HIP_H
+#define LCV_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LCV_OK 0
+#define LCV_EINVAL (-1)   /* bad shape / alignment / argument */
+#define LCV_EDEVICE (-2)  /* no gfx950 device or HIP runtime error */
+#define LCV_ELAUNCH (-3)  /* kernel launch failed */
+
+/* ---- library -------------------------------------------------------- */
+int lcv_version(void);                 /* ABI version (monotonic integer) */
+const char* lcv_last_error(void);      /* message of the last failure on this thread */
+/* 0 when the current device is gfx950; LCV_EDEVICE otherwise. */
+int lcv_device_check(void);
+
+/* ---- AdaLN modulate / LayerNorm ------------------------------------- */
+/* y = LN_noaffine_fp32(x) * (1 + scale[b,t,:]) + shift[b,t,:]  -> bf16
+ * x,y: [B, T*S, C] bf16 (S tokens per latent frame); shift/scale: fp32 rows of
+ * a [B, T, mod_stride] table (the adaLN_modulation output), addressed as
+ * mod + (b*T+t)*mod_stride + {shift_off,scale_off}.
+ * Replaces upstream modulate_fp32(mod_norm_*, x, shift, scale) reached from the
+ * block forward; layout evidence: delta_experiment/scripts/run_film_tta.py:5-12,134-141. */
+int lcv_adaln_modulate_fwd(const void* x, const float* mod, void* y,
+                           int64_t B, int64_t T, int64_t S, int64_t C,
+                           int64_t mod_stride, int64_t shift_off, int64_t scale_off,
+                           float eps, void* stream);
+/* Backward of the above w.r.t. x and (optionally) the modulation table.
+ * dx: bf16 [B,T*S,C]; dmod (nullable): fp32 [B,T,mod_stride], ACCUMULATED at
+ * shift_off / scale_off (caller zero-fills once per block). */
+int lcv_adaln_modulate_bwd(const void* x, const float* mod, const void* dy,
+                           void* dx, float* dmod,
+                           int64_t B, int64_t T, int64_t S, int64_t C,
+                           int64_t mod_stride, int64_t shift_off, int64_t scale_off,
+                           float eps, void* stream);
+/* y = LN_fp32(x) * w + b  (affine LayerNorm_FP32; pre_crs_attn_norm).
+ * Module name evidence: delta_experiment/scripts/run_norm_tune_tta.py:78-96. */
+int lcv_layernorm_affine_fwd(const void* x, const float* w, const float* b, void* y,
+                             int64_t rows, int64_t C, float eps, void* stream);
+/* dx (bf16) and, if non-NULL, dw/db fp32 [C] ACCUMULATED (atomics). */
+int lcv_layernorm_affine_bwd(const void* x, const float* w, const void* dy,
+                             void* dx, float* dw, float* db,
+                             int64_t rows, int64_t C, float eps, void* stream);
+
+/* ---- gated residual ------------------------------------------------- */
+/* out = bf16( f32(x) + gate[b,t,:] * f32(y) ); gate addressed like shift above.
+ * gate == NULL means gate = 1 (plain residual add, cross-attention branch). */
+int lcv_gate_residual_fwd(const void* x, const void* y, const float* mod, void* out,
+                          int64_t B, int64_t T, int64_t S, int64_t C,
+                          int64_t mod_stride, int64_t gate_off, void* stream);
+/* dy = gate*dout (bf16); dmod[gate_off] += sum_tokens(dout*y) (nullable). dx = dout (alias, not written). */
+int lcv_gate_residual_bwd(const void* y, const float* mod, const void* dout,
+                          void* dy, float* dmod,
+                          int64_t B, int64_t T, int64_t S, int64_t C,
+                          int64_t mod_stride, int64_t gate_off, void* stream);
+
+/* ---- q/k RMSNorm + 3-D RoPE ----------------------------------------- */
+/* For every token n and head h: q <- rope(rmsnorm(q)*wq), k <- rope(rmsnorm(k)*wk),
+ * v copied (skipped when v_out == NULL or v_out == v_in).
+ * Inputs are addressed as ptr + b*sb + n*sn + h*D (+d); D == 128.
+ * cs: [N_pos, D/2] float2 (cos, sin) table, row = pos_off + n (global position, so a
+ * sequence-parallel shard passes its own offset); cs == NULL skips RoPE
+ * (text cross-attention q/k norm).  RoPE pairs are interleaved (2i, 2i+1).
+ * Replaces upstream q_norm/k_norm/rope_3d inside Attention.forward
+ * (attribute names: lora_experiment/scripts/run_lora_tta.py:142-168). */
+int lcv_qknorm_rope_fwd(const void* q_in, const void* k_in, const void* v_in,
+                        void* q_out, void* k_out, void* v_out,
+                        const void* wq, const void* wk, const void* cs,
+                        int64_t B, int64_t N, int64_t H,
+                        int64_t in_sb, int64_t in_sn,       /* q_in/k_in/v_in strides */
+                        int64_t q_sb, int64_t q_sn,         /* q_out strides */
+                        int64_t kv_sb, int64_t kv_sn,       /* k_out/v_out strides */
+                        int64_t pos_off, float eps, void* stream);
+/* Backward: given dq_out, dk_out (same addressing as q_out/k_out) and the
+ * pre-norm q_in/k_in, writes dq_in, dk_in (addressing of q_in) ; dwq/dwk fp32 [D]
+ * accumulated when non-NULL. */
+int lcv_qknorm_rope_bwd(const void* q_in, const void* k_in,
+                        const void* dq_out, const void* dk_out,
+                        void* dq_in, void* dk_in,
+                        const void* wq, const void* wk, const void* cs,
+                        float* dwq, float* dwk,
+                        int64_t B, int64_t N, int64_t H,
+                        int64_t in_sb, int64_t in_sn,
+                        int64_t q_sb, int64_t q_sn,
+                        int64_t kv_sb, int64_t kv_sn,
+                        int64_t din_sb, int64_t din_sn,
+                        int64_t pos_off, float eps, void* stream);
+
+/* ---- flash attention (dense, non-causal, head_dim 128, bf16, fp32 acc) */
+/* o[b,n,h,:] = softmax(q k^T * scale) v ; q: Nq rows, k/v: Nk rows.
+ * Every tensor is addressed ptr + b*s_b + n*s_n + h*s_h + d with d contiguous.
+ * lse (nullable): fp32 [B, H, Nq] natural-log-sum-exp of the scaled scores.
+ * Replaces flash_attn_func / flash_attn_varlen_func requested by
+ * enable_flashattn2=True (delta_experiment/scripts/common.py:73); the
+ * conditioning split (cond-q x cond-kv, noise-q x all-kv) and the KV-cached
+ * denoise step are expressed by the caller through pointer offsets. */
+int lcv_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
+                 int64_t B, int64_t H, int64_t Nq, int64_t Nk,
+                 int64_t q_sb, int64_t q_sn, int64_t q_sh,
+                 int64_t k_sb, int64_t k_sn, int64_t k_sh,
+                 int64_t v_sb, int64_t v_sn, int64_t v_sh,
+                 int64_t o_sb, int64_t o_sn, int64_t o_sh,
+                 float scale, void* stream);
+/* Backward. delta_ws: fp32 workspace [B,H,Nq]; dq_acc: fp32 workspace
+ * [B,Nq,H,128] zero-filled by the callee; dq/dk/dv addressed like q/k/v. */
+int lcv_attn_bwd(const void* q, const void* k, const void* v, const void* o,
+                 const void* d_o, const float* lse,
+                 void* dq, void* dk, void* dv,
+                 float* delta_ws, float* dq_acc,
+                 int64_t B, int64_t H, int64_t Nq, int64_t Nk,
+                 int64_t q_sb, int64_t q_sn, int64_t q_sh,
+                 int64_t k_sb, int64_t k_sn, int64_t k_sh,
+                 int64_t v_sb, int64_t v_sn, int64_t v_sh,
+                 int64_t o_sb, int64_t o_sn, int64_t o_sh,
+                 int64_t dq_sb, int64_t dq_sn, int64_t dq_sh,
+                 int64_t dk_sb, int64_t dk_sn, int64_t dk_sh,
+                 int64_t dv_sb, int64_t dv_sn, int64_t dv_sh,
+                 float scale, void* stream);
+
+/* ---- projection GEMM (+ bias, + fused LoRA rank-r term, + epilogues) -- */
+#define LCV_EPI_NONE 0        /* c = acc + bias */
+#define LCV_EPI_SWIGLU 1      /* w rows interleaved [32 gate | 32 up]; c[M, N/2] = silu(g)*u */
+#define LCV_EPI_GATE_RESIDUAL 2 /* c = resid + gate[b,t,:]*(acc+bias) (fp32), rows are tokens */
+#define LCV_EPI_GELU_TANH 3   /* c = gelu_tanh(acc + bias) */
+#define LCV_EPI_SILU 4        /* c = silu(acc + bias) */
+/* c[M,N] = a[M,K] @ w[N,K]^T (+ bias[N]) (+ a2[M,K2] @ w2[N,K2]^T), bf16 in,
+ * fp32 accumulate, bf16 (out_f32 == 0) or fp32 out.  K % 64 == 0, K2 % 64 == 0
+ * (K2 = LoRA rank zero-padded to 64, a2 = s*(x A^T), w2 = B).  lda/ldw/ldc
+ * are row strides.  Replaces cuBLAS via nn.Linear for attn.qkv / attn.proj /
+ * cross_attn.{q_linear,kv_linear,proj} / ffn.w{1,2,3} / adaLN_modulation and the
+ * LoRALinear forward  (lora_experiment/scripts/run_lora_tta.py:224-260). */
+int lcv_gemm_nt(const void* a, const void* w, const void* bias,
+                const void* a2, const void* w2,
+                void* c, int64_t M, int64_t N, int64_t K, int64_t K2,
+                int64_t lda, int64_t ldw, int64_t lda2, int64_t ldw2, int64_t ldc,
+                int epilogue, int out_f32,
+                const void* resid, const float* mod, int64_t rows_per_frame,
+                int64_t mod_stride, int64_t gate_off,
+                void* stream);
+/* LoRA down-projection: h[M, Rpad] = bf16( s * bf16(x[M,K] @ A[R,K]^T) ), columns R..Rpad-1 zero.
+ * (lora_down of LoRALinear, run_lora_tta.py:247-260). */
+int lcv_lora_down(const void* x, const void* A, void* h, int64_t M, int64_t K, int64_t R,
+                  int64_t Rpad, int64_t ldx, float s, void* stream);
+/* LoRA-only backward pieces (no dW of the frozen base weight):
+ *   dB[N,R] (+)= dy[M,N]^T @ h[M,R]      (h = bf16(x A^T), unscaled; result scaled by s)
+ *   g[M,R]   =  s * dy[M,N] @ B[N,R]
+ *   dA[R,K] (+)= g[M,R]^T @ x[M,K]
+ * fp32 outputs, accumulated over row chunks by atomics; caller zero-fills. */
+int lcv_lora_bwd_dB_g(const void* dy, const void* h, const void* Bw, float* dB, void* g,
+                      int64_t M, int64_t N, int64_t R, int64_t Rpad, int64_t lddy, float s, void* stream);
+int lcv_lora_bwd_dA(const void* g, const void* x, float* dA,
+                    int64_t M, int64_t K, int64_t R, int64_t Rpad, int64_t ldx, void* stream);
+
+/* ---- SwiGLU --------------------------------------------------------- */
+int lcv_swiglu_fwd(const void* gate, const void* up, void* out, int64_t rows, int64_t F,
+                   int64_t ld_in, void* stream);
+int lcv_swiglu_bwd(const void* gate, const void* up, const void* dout, void* dgate, void* dup,
+                   int64_t rows, int64_t F, int64_t ld_in, void* stream);
+
+/* ---- patchify / unpatchify ------------------------------------------ */
+/* x [B,Cin,T,H,W] bf16 -> tokens [B, T*(H/2)*(W/2), Kpad] bf16, k = c*4 + ph*2 + pw (conv3d weight
+ * flattening order of x_embedder.proj, patch (1,2,2)); columns >= Cin*4 zero. */
+int lcv_patchify(const void* x, void* tok, int64_t B, int64_t Cin, int64_t T, int64_t H, int64_t W,
+                 int64_t Kpad, void* stream);
+/* tokens [B, N, 4*Cout] (ph, pw, c order; bf16 or fp32) -> out [B,Cout,T,H,W] fp32
+ * (upstream unpatchify; delta_experiment/scripts/run_delta_a.py:213-217). */
+int lcv_unpatchify(const void* tok, float* out, int64_t B, int64_t Cout, int64_t T, int64_t H, int64_t W,
+                   int tok_is_f32, void* stream);
+
+/* ---- denoise step glue ---------------------------------------------- */
+/* CFG-zero-star combine + sign + Euler update, fp32:
+ *   st = <c,u>/(<u,u>+1e-8) per sample (computed by the callee from the partial sums in ws),
+ *   v  = u*st + g*(c - u*st);  x <- x + dt * (negate ? -v : v)
+ * cond/uncond: fp32 [B, n]; x: fp32 [B, n] in place; ws: fp32 [B, 2] workspace. */
+int lcv_cfg_euler_step(const float* cond, const float* uncond, float* x, float* ws,
+                       int64_t B, int64_t n, float guidance, float dt, int negate,
+                       int use_zero_star, void* stream);
+/* x <- x + dt*v (no CFG). */
+int lcv_euler_step(const float* v, float* x, int64_t n, float dt, int negate, void* stream);
+
+/* ---- flow-matching loss pieces --------------------------------------- */
+/* noisy = (1-sigma)*x0 + sigma*eps (bf16 out), per-sample sigma fp32 [B].
+ * delta_experiment/scripts/common.py:458-466. */
+int lcv_fm_noise(const void* x0, const void* eps, const float* sigma, void* out,
+                 int64_t B, int64_t per_sample, void* stream);
+/* loss = mean( (pred[:,:,Tc:] - (eps - x0))^2 ) fp32, and dpred = 2/n * diff on the
+ * target slice, 0 on the cond slice.  pred fp32 [B,C,T,HW]; eps/x0 bf16 [B,C,Tt,HW].
+ * common.py:485-488.  loss_out: fp32 [1] (zero-filled by callee). dpred nullable. */
+int lcv_fm_mse(const float* pred, const void* eps, const void* x0, float* loss_out, float* dpred,
+               int64_t B, int64_t C, int64_t T, int64_t Tc, int64_t HW, void* stream);
+
+/* ---- fused multi-tensor AdamW + global-norm clip --------------------- */
+/* One descriptor per parameter tensor (device array of structs). */
+typedef struct {
+  void* param;      /* bf16 or fp32 (see param_f32) */
+  void* grad;       /* same dtype as param */
+  void* exp_avg;    /* same dtype as param */
+  void* exp_avg_sq; /* same dtype as param */
+  int64_t numel;
+} lcv_adam_tensor;
+/* sum of squares of all grads -> norm_sq[0] (fp32, zero-filled by callee). */
+int lcv_grad_norm_sq(const lcv_adam_tensor* tensors, int64_t n_tensors, int param_f32,
+                     float* norm_sq, void* stream);
+/* torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW.step (decoupled weight decay,
+ * bias correction, eps outside sqrt/bias2) in one launch; reads norm_sq[0].
+ * lora_experiment/scripts/run_lora_tta.py:462-468, 513-514. */
+int lcv_adamw_clip_step(const lcv_adam_tensor* tensors, int64_t n_tensors, int param_f32,
+                        const float* norm_sq, float max_norm, float lr, float beta1, float beta2,
+                        float eps, float weight_decay, int64_t step, void* stream);
+
+/* ---- VAE decoder stages (WAN-style causal 3-D conv VAE) -------------- */
+/* Causal conv3d, channels-last activations [B, T, H, W, Cin] bf16, weight
+ * [Cout, kt, kh, kw, Cin] bf16, bias [Cout]; temporal padding is causal
+ * (kt-1 frames in front, taken from `cache` [B, kt-1, H, W, Cin] when non-NULL,
+ * zeros otherwise), spatial padding (kh/2, kw/2) zeros.  out [B,T,H,W,Cout]. */
+int lcv_causal_conv3d(const void* x, const void* cache, const void* w, const void* bias, void* out,
+                      int64_t B, int64_t T, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
+                      int kt, int kh, int kw, void* stream);
+/* WAN RMS_norm over channels (channels-last): y = x / max(||x||_2,eps) * sqrt(C) * gamma[c], then optional SiLU. */
+int lcv_vae_rmsnorm_silu(const void* x, const void* gamma, void* y, int64_t rows, int64_t C,
+                         int apply_silu, void* stream);
+/* nearest-exact 2x spatial upsample, channels-last. */
+int lcv_upsample2x(const void* x, void* y, int64_t BT, int64_t H, int64_t W, int64_t C, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LCV_HIP_H */

@@ -1,0 +1,263 @@
+// Flash attention forward for the LongCat-Video DiT (dense, non-causal, D = 128, bf16 in,
+// fp32 accumulate).  One kernel serves 3-D self-attention (Nq = Nk = T*h*w), the
+// conditioning split (cond-q x cond-kv, noise-q x all-kv), the KV-cached denoise step and
+// the text cross-attention (Nk <= 512) through strides and pointer offsets.
+//
+// gfx950 structure
+//   * workgroup = 8 waves = 256 query rows of one (batch, head); each wave owns 32 rows.
+//     KV tile = 64 keys, K and V double-buffered in LDS (2 x 32 KiB), register-staged
+//     prefetch of tile t+1 issued before the MFMA work of tile t, one barrier per tile.
+//   * scores are computed TRANSPOSED, S^T = K Q^T (v_mfma_f32_32x32x16_bf16, A = K rows from
+//     LDS via ds_read_b128, B = Q held in registers).  The accumulator then has the query
+//     on the lane and the keys in the registers, so the softmax row max / row sum / rescale
+//     are lane-local (one cross-half exchange each), and the exponentiated tile is already
+//     the B operand of O^T += V^T P^T — P never touches LDS.
+//   * V^T fragments come from the row-major V tile with ds_read_b64_tr_b16; K and V share
+//     one XOR-swizzled 256-byte-row image that is conflict-free for both read kinds.
+//   * algorithmic work per launch: 4*Nq*Nk*128 flop and (Nq*2 + Nk*2)*128*2 bytes per (b, h).
+#include "lcv_common.h"
+
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+
+struct AttnFwdParams {
+  const bf16_t* q;
+  const bf16_t* k;
+  const bf16_t* v;
+  bf16_t* o;
+  float* lse;
+  int64_t Nq, Nk;
+  int H;
+  int64_t q_sb, q_sn, q_sh, k_sb, k_sn, k_sh, v_sb, v_sn, v_sh, o_sb, o_sn, o_sh;
+  float scale, scale_log2e;
+};
+
+// byte offset of 16-byte chunk `ch` (0..15) of row `row` in a [rows][128] bf16 tile
+__device__ __forceinline__ int tile_off(int row, int ch) {
+  return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+}
+
+template <int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnFwdParams p) {
+  constexpr int NT = NWAVES * 64;
+  constexpr int QROWS = NWAVES * 32;
+  constexpr int NCH = 1024 / NT;  // 16-byte chunks per thread per 64x128 tile
+  constexpr int TILE_BYTES = 64 * 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  lds_u8* lds = (lds_u8*)smem;  // [2][K tile | V tile]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int head = blockIdx.y;
+  const int64_t b = blockIdx.z;
+  const int64_t q0 = (int64_t)blockIdx.x * QROWS + wave * 32;
+
+  const bf16_t* kbase = p.k + b * p.k_sb + (int64_t)head * p.k_sh;
+  const bf16_t* vbase = p.v + b * p.v_sb + (int64_t)head * p.v_sh;
+
+  // ---- Q fragments (B operand): lane holds Q[q0 + r][16*ks + 8*h .. +8] ----
+  bf16x8 qf[8];
+  {
+    int64_t qrow = q0 + r;
+    if (qrow > p.Nq - 1) qrow = p.Nq - 1;
+    const bf16_t* qp = p.q + b * p.q_sb + qrow * p.q_sn + (int64_t)head * p.q_sh + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
+  }
+
+  // ---- staging roles: thread copies chunks c = tid + i*NT (row = c>>4, ch = c&15) ----
+  int st_off[NCH];
+  int st_row[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = tid + i * NT;
+    st_row[i] = c >> 4;
+    st_off[i] = tile_off(c >> 4, c & 15);
+  }
+  const int st_col = (tid & 15) * 8;
+  u32x4 kreg[NCH], vreg[NCH];
+  auto load_tile = [&](int64_t kv0) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      int64_t row = kv0 + st_row[i];
+      if (row > p.Nk - 1) row = p.Nk - 1;  // tail keys re-read the last row; they are masked below
+      kreg[i] = *reinterpret_cast<const u32x4*>(kbase + row * p.k_sn + st_col);
+      vreg[i] = *reinterpret_cast<const u32x4*>(vbase + row * p.v_sn + st_col);
+    }
+  };
+  auto store_tile = [&](int buf) {
+    lds_u8* kb = lds + buf * 2 * TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(kb + st_off[i]) = kreg[i];
+      *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(kb + TILE_BYTES + st_off[i]) = vreg[i];
+    }
+  };
+
+  // ---- per-lane LDS read addresses ----
+  const int kf = ((r & 3) << 2) | ((r >> 2) & 3);  // swizzle term of rows r and 32 + r
+  const int k_row_off = 256 * r;
+  // transposed V reads: lane = 16*g + 4*q4 + p4 ; supplies row q4, columns 4*p4..4*p4+3 of its block
+  const int q4 = (lane >> 2) & 3, p4 = lane & 3, g1 = (lane >> 4) & 1;
+  int v_base[2], v_low[2];
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    v_base[half] = 256 * (4 * h + 8 * half + q4) + 8 * (p4 & 1);
+    v_low[half] = (2 * g1 + (p4 >> 1)) ^ (h + 2 * half);
+  }
+
+  f32x16 oacc[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) oacc[d][e] = 0.f;
+  float m_run = -INFINITY;  // running max of the raw (unscaled) scores of this lane's query
+  float l_run = 0.f;        // this lane's partial row sum (its 32 of every 64 keys)
+
+  const int nt = (int)((p.Nk + 63) / 64);
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  for (int t = 0; t < nt; ++t) {
+    const int buf = t & 1;
+    const bool has_next = (t + 1 < nt);
+    if (has_next) load_tile((int64_t)(t + 1) * 64);
+
+    const lds_u8* kb = lds + buf * 2 * TILE_BYTES;
+    const lds_u8* vb = kb + TILE_BYTES;
+
+    // ---- S^T = K Q^T : two 32-key blocks ----
+    f32x16 s0, s1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { s0[e] = 0.f; s1[e] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const int co = 16 * ((2 * ks + h) ^ kf);
+      const bf16x8 a0 = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(kb + k_row_off + co);
+      const bf16x8 a1 = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(kb + 32 * 256 + k_row_off + co);
+      s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qf[ks], s0, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qf[ks], s1, 0, 0, 0);
+    }
+
+    // ---- mask keys past Nk (last tile only; wave-uniform branch) ----
+    if (!has_next && (p.Nk & 63)) {
+      const int valid = (int)(p.Nk - (int64_t)t * 64);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int key = (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (key >= valid) s0[e] = -INFINITY;
+        if (key + 32 >= valid) s1[e] = -INFINITY;
+      }
+    }
+
+    // ---- online softmax, lane-local except one cross-half exchange ----
+    float mx = fmaxf(s0[0], s1[0]);
+#pragma unroll
+    for (int e = 1; e < 16; ++e) mx = fmaxf(mx, fmaxf(s0[e], s1[e]));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.scale_log2e);  // first tile: exp2(-inf) = 0
+    const float mc = m_new * p.scale_log2e;
+    m_run = m_new;
+    float psum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      s0[e] = __builtin_amdgcn_exp2f(s0[e] * p.scale_log2e - mc);
+      s1[e] = __builtin_amdgcn_exp2f(s1[e] * p.scale_log2e - mc);
+      psum += s0[e] + s1[e];
+    }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
+
+    // ---- P^T as B operand: k-step kk covers keys 16*kk .. 16*kk+15 (permuted inside the step) ----
+    bf16x8 pb[4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      pb[0][j] = (__bf16)s0[j];
+      pb[1][j] = (__bf16)s0[8 + j];
+      pb[2][j] = (__bf16)s1[j];
+      pb[3][j] = (__bf16)s1[8 + j];
+    }
+
+    // ---- O^T += V^T P^T ----
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const int dx = 64 * (d ^ q4);
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(vb + v_base[0] + 4096 * kk + dx + 16 * v_low[0]));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(vb + v_base[1] + 4096 * kk + dx + 16 * v_low[1]));
+        // join the two 64-bit results as whole registers (an element-wise short->bf16 rebuild is
+        // miscompiled by hipcc 7.2 into a broadcast of element 0)
+        const bf16x8 vf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[kk], oacc[d], 0, 0, 0);
+      }
+    }
+
+    if (has_next) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue ----
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  const int64_t qrow = q0 + r;
+  if (qrow < p.Nq) {
+    bf16_t* op = p.o + b * p.o_sb + qrow * p.o_sn + (int64_t)head * p.o_sh;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        u16x4 pk;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pk[e] = f2bf(oacc[d][4 * i + e] * inv);
+        *reinterpret_cast<u16x4*>(op + 32 * d + 8 * i + 4 * h) = pk;
+      }
+    if (p.lse && h == 0) p.lse[(b * p.H + head) * p.Nq + qrow] = m_run * p.scale + __logf(l_tot);
+  }
+}
+
+extern "C" int lcv_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int64_t B,
+                            int64_t H, int64_t Nq, int64_t Nk, int64_t q_sb, int64_t q_sn, int64_t q_sh,
+                            int64_t k_sb, int64_t k_sn, int64_t k_sh, int64_t v_sb, int64_t v_sn,
+                            int64_t v_sh, int64_t o_sb, int64_t o_sn, int64_t o_sh, float scale,
+                            void* stream) {
+  LCV_CHECK_ARG(q && k && v && o, "attn_fwd: null pointer");
+  LCV_CHECK_ARG(B > 0 && H > 0 && H <= 65535 && B <= 65535, "attn_fwd: bad B/H");
+  LCV_CHECK_ARG(Nk > 0, "attn_fwd: Nk must be > 0 (empty key set has no softmax)");
+  LCV_CHECK_ARG(q_sn % 8 == 0 && k_sn % 8 == 0 && v_sn % 8 == 0 && q_sh % 8 == 0 && k_sh % 8 == 0 &&
+                    v_sh % 8 == 0 && q_sb % 8 == 0 && k_sb % 8 == 0 && v_sb % 8 == 0,
+                "attn_fwd: q/k/v strides must be multiples of 8 elements");
+  LCV_CHECK_ARG(o_sn % 4 == 0 && o_sh % 4 == 0 && o_sb % 4 == 0, "attn_fwd: o strides must be multiples of 4 elements");
+  LCV_CHECK_ARG(((uintptr_t)q % 16 == 0) && ((uintptr_t)k % 16 == 0) && ((uintptr_t)v % 16 == 0) && ((uintptr_t)o % 8 == 0),
+                "attn_fwd: pointers must be 16-byte aligned");
+  if (Nq == 0) return LCV_OK;
+  AttnFwdParams p;
+  p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.o = (bf16_t*)o; p.lse = lse;
+  p.Nq = Nq; p.Nk = Nk; p.H = (int)H;
+  p.q_sb = q_sb; p.q_sn = q_sn; p.q_sh = q_sh; p.k_sb = k_sb; p.k_sn = k_sn; p.k_sh = k_sh;
+  p.v_sb = v_sb; p.v_sn = v_sn; p.v_sh = v_sh; p.o_sb = o_sb; p.o_sn = o_sn; p.o_sh = o_sh;
+  p.scale = scale; p.scale_log2e = scale * 1.4426950408889634f;
+  constexpr int NW = 8;
+  const size_t lds = 2 * 2 * 64 * 256;
+  auto kern = attn_fwd_kernel<NW>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      lcv_set_error("attn_fwd: cannot raise dynamic LDS");
+      return LCV_EDEVICE;
+    }
+    attr_set = true;
+  }
+  const unsigned gx = (unsigned)((Nq + NW * 32 - 1) / (NW * 32));
+  hipLaunchKernelGGL(kern, dim3(gx, (unsigned)H, (unsigned)B), dim3(NW * 64), lds, (hipStream_t)stream, p);
+  LCV_LAUNCH_CHECK("attn_fwd");
+  return LCV_OK;
+}

@@ -1,0 +1,429 @@
+// Projection GEMM for the DiT linears:  C[M,N] = A[M,K] W[N,K]^T (+ A2[M,K2] W2[N,K2]^T) + bias
+// bf16 operands, fp32 accumulation on v_mfma_f32_32x32x16_bf16, fused epilogues.
+//
+// Structure (gfx950):
+//   * BM x BN output tile per workgroup, BK = 64; waves laid out WR x WC, each owning
+//     (BM/WR) x (BN/WC) as TM x TN MFMA tiles of 32x32.
+//   * both operands are K-contiguous ("NT"): an nn.Linear weight [out,in] is used as stored.
+//     The backward dx = dy W uses a resident transposed copy of W (288 GB HBM: 2x27 GB of
+//     weights is cheap) so the same kernel serves forward and backward.
+//   * global -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction),
+//     two LDS buffers; the LDS image is lane-linear, the XOR swizzle that makes the
+//     ds_read_b128 fragment reads conflict-free is applied to the SOURCE address and to
+//     the read address (same involution on both sides).
+//   * the rank-r LoRA term is one extra 64-deep K-step fed from (a2, w2): zero epilogue cost.
+//   * XCD-aware block order: consecutive workgroup ids on one XCD walk down M inside one
+//     N panel, so the W panel stays in that XCD's L2.
+#include "lcv_common.h"
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gbl_void;
+
+struct GemmParams {
+  const bf16_t* a;
+  const bf16_t* w;
+  const bf16_t* bias;
+  const bf16_t* a2;
+  const bf16_t* w2;
+  void* c;
+  int64_t M, N;
+  int nk1, nk2;  // 64-deep K tiles of (a,w) and (a2,w2)
+  int64_t lda, ldw, lda2, ldw2, ldc;
+  int out_f32;
+  const bf16_t* resid;
+  const float* gate;  // mod + gate_off
+  int64_t rows_per_frame, mod_stride;
+  int tiles_m, tiles_n;
+};
+
+template <int BM, int BN, int WR, int WC>
+struct GemmCfg {
+  static constexpr int NW = WR * WC;
+  static constexpr int NT = NW * 64;
+  static constexpr int TM = BM / WR / 32;
+  static constexpr int TN = BN / WC / 32;
+  static constexpr int A_BYTES = BM * 128;
+  static constexpr int B_BYTES = BN * 128;
+  static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+  static constexpr int IA = BM / 8 / NW;  // LDS-DMA wave-instructions per wave for the A tile
+  static constexpr int IB = BN / 8 / NW;
+};
+
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+  const float k = 0.7978845608028654f;
+  const float inner = k * (x + 0.044715f * x * x * x);
+  return 0.5f * x * (1.0f + tanhf(inner));
+}
+
+template <int BM, int BN, int WR, int WC, int EPI>
+__global__ __launch_bounds__(WR* WC * 64) void gemm_nt_kernel(const GemmParams p) {
+  using Cfg = GemmCfg<BM, BN, WR, WC>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  // ---- XCD-aware tile order: ids that share an XCD (id % 8) get a contiguous run ----
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int orig = blockIdx.x;
+  const int xcd = orig & 7;
+  const int q = nwg >> 3, r8 = nwg & 7;
+  const int wgid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (orig >> 3);
+  const int tn = wgid / p.tiles_m;  // M fastest inside an N panel
+  const int tm = wgid - tn * p.tiles_m;
+  const int64_t m0 = (int64_t)tm * BM;
+  const int64_t n0 = (int64_t)tn * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave / WC, wc = wave % WC;
+  const int r = lane & 31, h = lane >> 5;
+
+  // ---- per-lane source rows for the LDS-DMA (clamped: tails re-read the last valid row) ----
+  const int ld_row = lane >> 3, ld_slot = lane & 7;
+  int64_t a_row[Cfg::IA], b_row[Cfg::IB];
+  int a_sw[Cfg::IA], b_sw[Cfg::IB];
+#pragma unroll
+  for (int t = 0; t < Cfg::IA; ++t) {
+    const int row = (wave * Cfg::IA + t) * 8 + ld_row;
+    int64_t g = m0 + row;
+    if (g > p.M - 1) g = p.M - 1;
+    a_row[t] = g;
+    a_sw[t] = (ld_slot ^ ((row >> 1) & 7)) * 8;
+  }
+#pragma unroll
+  for (int t = 0; t < Cfg::IB; ++t) {
+    const int row = (wave * Cfg::IB + t) * 8 + ld_row;
+    int64_t g = n0 + row;
+    if (g > p.N - 1) g = p.N - 1;
+    b_row[t] = g;
+    b_sw[t] = (ld_slot ^ ((row >> 1) & 7)) * 8;
+  }
+
+  auto stage = [&](int kt, int buf) {
+    const bf16_t* A = p.a;
+    const bf16_t* W = p.w;
+    int64_t lda = p.lda, ldw = p.ldw;
+    int k0 = kt * 64;
+    if (kt >= p.nk1) {
+      A = p.a2; W = p.w2; lda = p.lda2; ldw = p.ldw2; k0 = (kt - p.nk1) * 64;
+    }
+    unsigned char* sa = smem + buf * Cfg::STAGE_BYTES;
+    unsigned char* sb = sa + Cfg::A_BYTES;
+#pragma unroll
+    for (int t = 0; t < Cfg::IA; ++t) {
+      const bf16_t* src = A + a_row[t] * lda + k0 + a_sw[t];
+      __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(sa + (wave * Cfg::IA + t) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < Cfg::IB; ++t) {
+      const bf16_t* src = W + b_row[t] * ldw + k0 + b_sw[t];
+      __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(sb + (wave * Cfg::IB + t) * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[Cfg::TM][Cfg::TN];
+#pragma unroll
+  for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+    for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int sw = (r >> 1) & 7;
+  const int a_off = (wr * (BM / WR) + r) * 128;
+  const int b_off = (wc * (BN / WC) + r) * 128;
+  const int nk = p.nk1 + p.nk2;
+
+  stage(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();  // drains this wave's LDS-DMA (vmcnt 0) and orders buffer reuse
+    if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+    const unsigned char* sa = smem + (kt & 1) * Cfg::STAGE_BYTES;
+    const unsigned char* sb = sa + Cfg::A_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int ch = ((2 * ks + h) ^ sw) * 16;
+      bf16x8 af[Cfg::TM], bfr[Cfg::TN];
+#pragma unroll
+      for (int i = 0; i < Cfg::TM; ++i)
+        af[i] = *reinterpret_cast<const bf16x8*>(sa + a_off + i * 32 * 128 + ch);
+#pragma unroll
+      for (int j = 0; j < Cfg::TN; ++j)
+        bfr[j] = *reinterpret_cast<const bf16x8*>(sb + b_off + j * 32 * 128 + ch);
+#pragma unroll
+      for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < Cfg::TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: acc[i][j][e] is C[row = (e&3)+8*(e>>2)+4*h][col = lane&31] of its 32x32 tile ----
+  const int64_t mw = m0 + wr * (BM / WR);
+  const int64_t nw = n0 + wc * (BN / WC);
+  if constexpr (EPI == LCV_EPI_SWIGLU) {
+    // W rows interleaved [32 gate | 32 up]: tile j even = gate, j odd = up of the same 32 features
+    bf16_t* C = (bf16_t*)p.c;
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+      for (int jj = 0; jj < Cfg::TN / 2; ++jj) {
+        const int64_t ng = nw + jj * 64 + r;  // gate column in the interleaved weight
+        if (ng >= p.N) continue;
+        const float bg = p.bias ? bf2f(p.bias[ng]) : 0.f;
+        const float bu = p.bias ? bf2f(p.bias[ng + 32]) : 0.f;
+        const int64_t f = (nw + jj * 64) / 2 + r;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int64_t m = mw + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (m < p.M) {
+            const float g = bfround(acc[i][2 * jj][e] + bg);
+            const float u = bfround(acc[i][2 * jj + 1][e] + bu);
+            C[m * p.ldc + f] = f2bf(bfround(silu_f(g)) * u);
+          }
+        }
+      }
+  } else {
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+      for (int j = 0; j < Cfg::TN; ++j) {
+        const int64_t n = nw + j * 32 + r;
+        if (n >= p.N) continue;
+        const float b = p.bias ? bf2f(p.bias[n]) : 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int64_t m = mw + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (m < p.M) {
+            float v = acc[i][j][e] + b;
+            if constexpr (EPI == LCV_EPI_GATE_RESIDUAL) {
+              const float xs = bfround(v);  // the projection output is a bf16 tensor upstream
+              const float g = p.gate ? p.gate[(m / p.rows_per_frame) * p.mod_stride + n] : 1.0f;
+              v = bf2f(p.resid[m * p.ldc + n]) + g * xs;
+            } else if constexpr (EPI == LCV_EPI_GELU_TANH) {
+              v = gelu_tanh_f(bfround(v));
+            } else if constexpr (EPI == LCV_EPI_SILU) {
+              v = silu_f(bfround(v));
+            }
+            if (p.out_f32) ((float*)p.c)[m * p.ldc + n] = v;
+            else ((bf16_t*)p.c)[m * p.ldc + n] = f2bf(v);
+          }
+        }
+      }
+  }
+}
+
+template <int BM, int BN, int WR, int WC, int EPI>
+static int launch_gemm(GemmParams& p, hipStream_t s) {
+  using Cfg = GemmCfg<BM, BN, WR, WC>;
+  p.tiles_m = (int)((p.M + BM - 1) / BM);
+  p.tiles_n = (int)((p.N + BN - 1) / BN);
+  const size_t lds = 2 * Cfg::STAGE_BYTES;
+  auto kern = gemm_nt_kernel<BM, BN, WR, WC, EPI>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      lcv_set_error("gemm_nt: cannot raise dynamic LDS to %zu", lds);
+      return LCV_EDEVICE;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(Cfg::NT), lds, s, p);
+  LCV_LAUNCH_CHECK("gemm_nt");
+  return LCV_OK;
+}
+
+template <int EPI>
+static int dispatch_tile(GemmParams& p, hipStream_t s) {
+  // 256x256 tiles for the big token-side projections, 128x128 otherwise (small M or N).
+  static const char* force = getenv("LCV_GEMM_TILE");
+  bool big = p.M >= 2048 && p.N >= 1024;
+  if (force) big = (force[0] == '2');
+  if (big) return launch_gemm<256, 256, 2, 4, EPI>(p, s);
+  return launch_gemm<128, 128, 2, 2, EPI>(p, s);
+}
+
+extern "C" int lcv_gemm_nt(const void* a, const void* w, const void* bias, const void* a2, const void* w2,
+                           void* c, int64_t M, int64_t N, int64_t K, int64_t K2, int64_t lda, int64_t ldw,
+                           int64_t lda2, int64_t ldw2, int64_t ldc, int epilogue, int out_f32,
+                           const void* resid, const float* mod, int64_t rows_per_frame, int64_t mod_stride,
+                           int64_t gate_off, void* stream) {
+  LCV_CHECK_ARG(a && w && c, "gemm_nt: null pointer");
+  LCV_CHECK_ARG(M >= 0 && N > 0 && K > 0 && K % 64 == 0, "gemm_nt: K=%ld must be a positive multiple of 64", (long)K);
+  LCV_CHECK_ARG(K2 >= 0 && K2 % 64 == 0, "gemm_nt: K2=%ld must be a multiple of 64", (long)K2);
+  LCV_CHECK_ARG(K2 == 0 || (a2 && w2), "gemm_nt: K2 > 0 needs a2 and w2");
+  LCV_CHECK_ARG(lda % 8 == 0 && ldw % 8 == 0 && (K2 == 0 || (lda2 % 8 == 0 && ldw2 % 8 == 0)),
+                "gemm_nt: operand row strides must be multiples of 8 elements (16 bytes)");
+  LCV_CHECK_ARG(((uintptr_t)a % 16 == 0) && ((uintptr_t)w % 16 == 0), "gemm_nt: operands must be 16-byte aligned");
+  if (M == 0) return LCV_OK;
+  GemmParams p;
+  p.a = (const bf16_t*)a; p.w = (const bf16_t*)w; p.bias = (const bf16_t*)bias;
+  p.a2 = (const bf16_t*)a2; p.w2 = (const bf16_t*)w2; p.c = c;
+  p.M = M; p.N = N; p.nk1 = (int)(K / 64); p.nk2 = (int)(K2 / 64);
+  p.lda = lda; p.ldw = ldw; p.lda2 = lda2; p.ldw2 = ldw2; p.ldc = ldc; p.out_f32 = out_f32;
+  p.resid = (const bf16_t*)resid; p.gate = mod ? mod + gate_off : nullptr;
+  p.rows_per_frame = rows_per_frame > 0 ? rows_per_frame : 1; p.mod_stride = mod_stride;
+  hipStream_t s = (hipStream_t)stream;
+  switch (epilogue) {
+    case LCV_EPI_NONE: return dispatch_tile<LCV_EPI_NONE>(p, s);
+    case LCV_EPI_SWIGLU:
+      LCV_CHECK_ARG(N % 64 == 0 && !out_f32, "gemm_nt: SwiGLU epilogue needs N %% 64 == 0 and bf16 output");
+      return dispatch_tile<LCV_EPI_SWIGLU>(p, s);
+    case LCV_EPI_GATE_RESIDUAL:
+      LCV_CHECK_ARG(resid != nullptr, "gemm_nt: gate-residual epilogue needs resid");
+      return dispatch_tile<LCV_EPI_GATE_RESIDUAL>(p, s);
+    case LCV_EPI_GELU_TANH: return dispatch_tile<LCV_EPI_GELU_TANH>(p, s);
+    case LCV_EPI_SILU: return dispatch_tile<LCV_EPI_SILU>(p, s);
+    default:
+      lcv_set_error("gemm_nt: unknown epilogue %d", epilogue);
+      return LCV_EINVAL;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Small-M fp32 linear for the fp32 islands (t_embedder MLP, adaLN_modulation):
+//   out[M,N] fp32 = act_in(a[M,K] fp32) @ W[N,K]^T (bf16 weights widened) + bias
+// HBM-bound on the weight stream (adaLN: 24576 x 512 x 2 B = 25 MB per block);
+// one wave per output column, activations staged once per workgroup in LDS.
+// ---------------------------------------------------------------------------
+template <int MAXM>
+__global__ __launch_bounds__(256) void linear_f32_smallm_kernel(const float* __restrict__ a,
+                                                                const bf16_t* __restrict__ w,
+                                                                const bf16_t* __restrict__ bias,
+                                                                float* __restrict__ out, int M, int64_t N,
+                                                                int K, int act_in, int cols_per_wave) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* sa = reinterpret_cast<float*>(smem);  // [M][K]
+  for (int i = threadIdx.x; i < M * K; i += 256) {
+    float v = a[i];
+    if (act_in == 1) v = silu_f(v);
+    sa[i] = v;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int64_t nbase = ((int64_t)blockIdx.x * 4 + wave) * cols_per_wave;
+  for (int cc = 0; cc < cols_per_wave; ++cc) {
+    const int64_t n = nbase + cc;
+    if (n >= N) return;
+    float acc[MAXM];
+#pragma unroll
+    for (int m = 0; m < MAXM; ++m) acc[m] = 0.f;
+    for (int k = lane * 8; k < K; k += 512) {
+      float wf[8];
+      unpack8(*reinterpret_cast<const u16x8*>(w + n * K + k), wf);
+#pragma unroll
+      for (int m = 0; m < MAXM; ++m) {
+        if (m < M) {
+          const f32x4 x0 = *reinterpret_cast<const f32x4*>(sa + m * K + k);
+          const f32x4 x1 = *reinterpret_cast<const f32x4*>(sa + m * K + k + 4);
+          acc[m] += x0[0] * wf[0] + x0[1] * wf[1] + x0[2] * wf[2] + x0[3] * wf[3] + x1[0] * wf[4] +
+                    x1[1] * wf[5] + x1[2] * wf[6] + x1[3] * wf[7];
+        }
+      }
+    }
+    const float b = bias ? bf2f(bias[n]) : 0.f;
+#pragma unroll
+    for (int m = 0; m < MAXM; ++m) {
+      if (m < M) {
+        const float s = wave_sum(acc[m]);
+        if (lane == 0) out[(int64_t)m * N + n] = s + b;
+      }
+    }
+  }
+}
+
+extern "C" int lcv_linear_f32_smallm(const float* a, const void* w, const void* bias, float* out, int64_t M,
+                                     int64_t N, int64_t K, int act_in, void* stream) {
+  LCV_CHECK_ARG(a && w && out, "linear_f32_smallm: null pointer");
+  LCV_CHECK_ARG(K % 8 == 0 && K > 0 && N > 0, "linear_f32_smallm: K must be a positive multiple of 8");
+  hipStream_t s = (hipStream_t)stream;
+  // rows are processed in groups of <= 16 so the staged activations stay <= 64 KiB of LDS
+  const int64_t max_rows = 16;
+  LCV_CHECK_ARG(max_rows * K * 4 <= 160 * 1024, "linear_f32_smallm: K=%ld too large", (long)K);
+  for (int64_t m0 = 0; m0 < M; m0 += max_rows) {
+    const int Mc = (int)((M - m0) < max_rows ? (M - m0) : max_rows);
+    const size_t lds = (size_t)Mc * K * 4;
+    const int cols_per_wave = 4;
+    const unsigned grid = (unsigned)((N + 4 * cols_per_wave - 1) / (4 * cols_per_wave));
+    auto kern = linear_f32_smallm_kernel<16>;
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        lcv_set_error("linear_f32_smallm: cannot raise dynamic LDS");
+        return LCV_EDEVICE;
+      }
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a + m0 * K, (const bf16_t*)w, (const bf16_t*)bias,
+                       out + m0 * N, Mc, N, (int)K, act_in, cols_per_wave);
+    LCV_LAUNCH_CHECK("linear_f32_smallm");
+  }
+  return LCV_OK;
+}
+
+// ---------------------------------------------------------------------------
+// LoRA down-projection: h[M,Rpad] = bf16( s * bf16( x[M,K] A[R,K]^T ) ), zero padded.
+// HBM-bound on x (rank r flop/B): one wave per row, A held in LDS.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lora_down_kernel(const bf16_t* __restrict__ x,
+                                                        const bf16_t* __restrict__ A,
+                                                        bf16_t* __restrict__ hout, int64_t M, int K, int R,
+                                                        int Rpad, int64_t ldx, float s) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16_t* sA = reinterpret_cast<bf16_t*>(smem);  // [R][K]
+  for (int i = threadIdx.x * 8; i < R * K; i += 256 * 8)
+    *reinterpret_cast<u16x8*>(sA + i) = *reinterpret_cast<const u16x8*>(A + i);
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < M; row += (int64_t)gridDim.x * 4) {
+    float acc[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) acc[j] = 0.f;
+    for (int k = lane * 8; k < K; k += 512) {
+      float xf[8];
+      unpack8(*reinterpret_cast<const u16x8*>(x + row * ldx + k), xf);
+#pragma unroll
+      for (int j = 0; j < 32; ++j) {
+        if (j < R) {
+          float af[8];
+          unpack8(*reinterpret_cast<const u16x8*>(sA + j * K + k), af);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[j] += xf[e] * af[e];
+        }
+      }
+    }
+    float mine = 0.f;  // lane j keeps column j
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      if (j < R) {
+        const float t = wave_sum(acc[j]);
+        if (lane == j) mine = t;
+      }
+    }
+    if (lane < Rpad) hout[row * Rpad + lane] = (lane < R) ? f2bf(s * bfround(mine)) : (bf16_t)0;
+  }
+}
+
+extern "C" int lcv_lora_down(const void* x, const void* A, void* h, int64_t M, int64_t K, int64_t R,
+                             int64_t Rpad, int64_t ldx, float s, void* stream) {
+  LCV_CHECK_ARG(x && A && h, "lora_down: null pointer");
+  LCV_CHECK_ARG(R >= 1 && R <= 32 && Rpad >= R && Rpad <= 64, "lora_down: rank %ld unsupported (1..32, Rpad <= 64)", (long)R);
+  LCV_CHECK_ARG(K % 8 == 0 && ldx % 8 == 0 && R * K * 2 <= 160 * 1024 - 1024, "lora_down: bad K");
+  if (M == 0) return LCV_OK;
+  const size_t lds = (size_t)R * K * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)lora_down_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024) != hipSuccess) {
+      lcv_set_error("lora_down: cannot raise dynamic LDS");
+      return LCV_EDEVICE;
+    }
+    attr_set = true;
+  }
+  int64_t blocks = (M + 3) / 4;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(lora_down_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream,
+                     (const bf16_t*)x, (const bf16_t*)A, (bf16_t*)h, M, (int)K, (int)R, (int)Rpad, ldx, s);
+  LCV_LAUNCH_CHECK("lora_down");
+  return LCV_OK;
+}

@@ -1,0 +1,93 @@
+"""ctypes binding of liblcv_hip.so (the C ABI declared in include/lcv_hip.h).
+
+The library is the product path: when it is missing this module raises — there
+is no CPU or eager-PyTorch fallback anywhere above it.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+from pathlib import Path
+
+_LIB_PATH = Path(__file__).resolve().parent / "liblcv_hip.so"
+
+P, I64, F32, I = c_void_p, c_int64, c_float, c_int
+
+# name -> argtypes (every function returns int)
+_SIGNATURES = {
+    "lcv_device_check": [],
+    "lcv_adaln_modulate_fwd": [P, P, P, I64, I64, I64, I64, I64, I64, I64, F32, P],
+    "lcv_adaln_modulate_bwd": [P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, F32, P],
+    "lcv_layernorm_affine_fwd": [P, P, P, P, I64, I64, F32, P],
+    "lcv_layernorm_affine_bwd": [P, P, P, P, P, P, I64, I64, F32, P],
+    "lcv_gate_residual_fwd": [P, P, P, P, I64, I64, I64, I64, I64, I64, P],
+    "lcv_gate_residual_bwd": [P, P, P, P, P, I64, I64, I64, I64, I64, I64, P],
+    "lcv_qknorm_rope_fwd": [P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, F32, P],
+    "lcv_qknorm_rope_bwd": [P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64,
+                            I64, I64, I64, F32, P],
+    "lcv_attn_fwd": [P, P, P, P, P, I64, I64, I64, I64] + [I64] * 12 + [F32, P],
+    "lcv_attn_bwd": [P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64] + [I64] * 21 + [F32, P],
+    "lcv_gemm_nt": [P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, I, I, P, P, I64, I64, I64, P],
+    "lcv_linear_f32_smallm": [P, P, P, P, I64, I64, I64, I, P],
+    "lcv_lora_down": [P, P, P, I64, I64, I64, I64, I64, F32, P],
+    "lcv_lora_bwd_dB_g": [P, P, P, P, P, I64, I64, I64, I64, I64, F32, P],
+    "lcv_lora_bwd_dA": [P, P, P, I64, I64, I64, I64, I64, P],
+    "lcv_swiglu_fwd": [P, P, P, I64, I64, I64, P],
+    "lcv_swiglu_bwd": [P, P, P, P, P, I64, I64, I64, P],
+    "lcv_patchify": [P, P, I64, I64, I64, I64, I64, I64, P],
+    "lcv_unpatchify": [P, P, I64, I64, I64, I64, I64, I, P],
+    "lcv_cfg_euler_step": [P, P, P, P, I64, I64, F32, F32, I, I, P],
+    "lcv_euler_step": [P, P, I64, F32, I, P],
+    "lcv_fm_noise": [P, P, P, P, I64, I64, P],
+    "lcv_fm_mse": [P, P, P, P, P, I64, I64, I64, I64, I64, P],
+    "lcv_grad_norm_sq": [P, I64, I, P, P],
+    "lcv_adamw_clip_step": [P, I64, I, P, F32, F32, F32, F32, F32, F32, I64, P],
+    "lcv_causal_conv3d": [P, P, P, P, P, I64, I64, I64, I64, I64, I64, I, I, I, P],
+    "lcv_vae_rmsnorm_silu": [P, P, P, I64, I64, I, P],
+    "lcv_upsample2x": [P, P, I64, I64, I64, I64, P],
+}
+
+LCV_EPI_NONE, LCV_EPI_SWIGLU, LCV_EPI_GATE_RESIDUAL, LCV_EPI_GELU_TANH, LCV_EPI_SILU = 0, 1, 2, 3, 4
+
+
+class LcvError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib_path() -> Path:
+    return _LIB_PATH
+
+
+def load():
+    """Load the shared library once; raise loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not _LIB_PATH.exists():
+        raise LcvError(
+            f"{_LIB_PATH} is missing: build it with `python __graft_entry__.py` (hipcc, gfx950). "
+            "There is no fallback path.")
+    lib = ctypes.CDLL(str(_LIB_PATH), mode=os.RTLD_NOW | getattr(os, "RTLD_LOCAL", 0))
+    lib.lcv_version.restype = c_int
+    lib.lcv_version.argtypes = []
+    lib.lcv_last_error.restype = c_char_p
+    lib.lcv_last_error.argtypes = []
+    for name, args in _SIGNATURES.items():
+        fn = getattr(lib, name, None)
+        if fn is None:
+            continue  # export coverage is asserted by tests/test_abi.py against include/lcv_hip.h
+        fn.restype = c_int
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def call(name: str, *args):
+    lib = load()
+    fn = getattr(lib, name)
+    rc = fn(*args)
+    if rc != 0:
+        msg = lib.lcv_last_error()
+        raise LcvError(f"{name} failed ({rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,217 @@
+"""GPU parity: every forward kernel, through the C ABI, against the CPU oracle (oracle/dit_oracle.py).
+
+Tolerances (stated per test): kernels whose outputs are bf16 are compared with the oracle evaluated at the
+same bf16 rounding points; the remaining difference is fp32 summation order, which can flip the last bf16
+bit of an element, so the bar is relative-L2 <= 2e-3 (bf16 epsilon is 7.8e-3) and max |diff| <= 2 bf16 ulps
+of the output scale.  Integer/index results and the fp32-exact elementwise pieces are bit-exact.
+"""
+import math
+
+import pytest
+import torch
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+BF16 = torch.bfloat16
+DEV = "cuda"
+
+
+def _ops():
+    from lcv_hip import ops
+    return ops
+
+
+def _orc():
+    from oracle import dit_oracle
+    return dit_oracle
+
+
+def _randn(*shape, seed=0, scale=1.0, dtype=BF16):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype)
+
+
+def test_device_is_gfx950():
+    from lcv_hip import lib
+    lib.call("lcv_device_check")
+    assert lib.load().lcv_version() >= 1
+
+
+@pytest.mark.parametrize("B,T,S,C", [(2, 3, 40, 512), (1, 2, 7, 4096), (1, 1, 5, 128)])
+def test_adaln_modulate(B, T, S, C):
+    ops, orc = _ops(), _orc()
+    x = _randn(B, T * S, C, seed=1)
+    mod = _randn(B, T, 6 * C, seed=2, scale=0.5, dtype=torch.float32)
+    y = ops.adaln_modulate(x.to(DEV), mod.to(DEV), 3, 4, T)
+    sh, sc = mod[..., 3 * C:4 * C].unsqueeze(2), mod[..., 4 * C:5 * C].unsqueeze(2)
+    ref = orc.modulate_fp32(x.view(B, T, S, C), sh, sc, rnd=orc.bf16_round).view(B, T * S, C)
+    assert rel_l2(y, ref) < 2e-3
+    assert (y.float().cpu() - ref).abs().max() <= 2 * 2 ** -7 * ref.abs().max()
+
+
+def test_layernorm_affine():
+    ops, orc = _ops(), _orc()
+    x = _randn(3, 50, 1024, seed=3)
+    w = _randn(1024, seed=4); b = _randn(1024, seed=5)
+    y = ops.layernorm_affine(x.to(DEV), w.to(DEV), b.to(DEV))
+    ref = orc.bf16_round(orc.layernorm_fp32(x, w, b))
+    assert rel_l2(y, ref) < 2e-3
+
+
+def test_gate_residual():
+    ops, orc = _ops(), _orc()
+    B, T, S, C = 2, 3, 11, 256
+    x = _randn(B, T * S, C, seed=6); y = _randn(B, T * S, C, seed=7)
+    mod = _randn(B, T, 6 * C, seed=8, dtype=torch.float32)
+    out = ops.gate_residual(x.to(DEV), y.to(DEV), mod.to(DEV), 2, T)
+    g = mod[..., 2 * C:3 * C].unsqueeze(2)
+    ref = orc.bf16_round(x.float() + (g * y.float().view(B, T, S, C)).view(B, T * S, C))
+    # same fp32 expression evaluated once: only fma contraction can differ
+    assert rel_l2(out, ref) < 1e-3
+    out2 = ops.gate_residual(x.to(DEV), y.to(DEV), None, 0, 1)
+    assert torch.equal(out2.cpu(), (x.float() + y.float()).to(BF16))
+
+
+@pytest.mark.parametrize("grid,H", [((2, 3, 5), 16), ((1, 4, 4), 32)])
+def test_qknorm_rope(grid, H):
+    ops, orc = _ops(), _orc()
+    N = grid[0] * grid[1] * grid[2]
+    B, D = 2, 128
+    qkv = _randn(B, N, 3, H, D, seed=9)
+    wq = (1 + 0.1 * _randn(D, seed=10).float()).to(BF16); wk = (1 + 0.1 * _randn(D, seed=11).float()).to(BF16)
+    cs = orc.rope_cos_sin_table(grid, D)
+    d = qkv.to(DEV)
+    ops.qknorm_rope(d[:, :, 0], d[:, :, 1], None, d[:, :, 0], d[:, :, 1], None, wq.to(DEV), wk.to(DEV), cs.to(DEV))
+    ang = orc.rope_angles_3d(grid, D)
+    for idx, w in ((0, wq), (1, wk)):
+        src = qkv[:, :, idx].permute(0, 2, 1, 3)  # [B,H,N,D]
+        ref = orc.apply_rope(orc.rmsnorm_fp32(src, w, rnd=orc.bf16_round), ang, orc.bf16_round)
+        got = d[:, :, idx].permute(0, 2, 1, 3)
+        assert rel_l2(got, ref) < 2e-3, idx
+    assert torch.equal(d[:, :, 2].cpu(), qkv[:, :, 2])  # V untouched
+
+
+@pytest.mark.parametrize("B,H,Nq,Nk", [(1, 2, 300, 300), (2, 1, 64, 77), (1, 1, 513, 1000), (1, 2, 256, 64), (1, 1, 31, 5)])
+def test_attention(B, H, Nq, Nk):
+    ops, orc = _ops(), _orc()
+    D = 128
+    q = _randn(B, Nq, H, D, seed=12); k = _randn(B, Nk, H, D, seed=13); v = _randn(B, Nk, H, D, seed=14)
+    scale = D ** -0.5
+    o, lse = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), scale, need_lse=True)
+    ref = orc.sdpa(q.permute(0, 2, 1, 3), k.permute(0, 2, 1, 3), v.permute(0, 2, 1, 3), scale)  # fp32
+    # tolerance: P is rounded to bf16 before PV (as flash-attn does) and O is stored in bf16
+    assert rel_l2(o.permute(0, 2, 1, 3), ref) < 6e-3
+    s = (q.permute(0, 2, 1, 3).float() @ k.permute(0, 2, 1, 3).float().transpose(-1, -2)) * scale
+    assert torch.allclose(lse.cpu(), torch.logsumexp(s, dim=-1), atol=2e-4, rtol=1e-5)
+
+
+def test_attention_strided_packed_qkv_and_spike():
+    """q/k/v as views of a packed [B,N,3,H,D] buffer; one key row spiked so the running max jumps mid-stream."""
+    ops, orc = _ops(), _orc()
+    B, N, H, D = 1, 400, 2, 128
+    qkv = _randn(B, N, 3, H, D, seed=15)
+    qkv[0, 300, 1] *= 8.0
+    d = qkv.to(DEV)
+    o, _ = ops.attention(d[:, :, 0], d[:, :, 1], d[:, :, 2], D ** -0.5)
+    ref = orc.sdpa(qkv[:, :, 0].permute(0, 2, 1, 3), qkv[:, :, 1].permute(0, 2, 1, 3), qkv[:, :, 2].permute(0, 2, 1, 3), D ** -0.5)
+    assert rel_l2(o.permute(0, 2, 1, 3), ref) < 6e-3
+
+
+@pytest.mark.parametrize("M,N,K,tile", [(300, 192, 128, "1"), (70, 64, 64, "1"), (2050, 1024, 256, "2"), (513, 768, 192, "2")])
+def test_gemm_nt_bias(M, N, K, tile, monkeypatch):
+    monkeypatch.setenv("LCV_GEMM_TILE", tile)
+    ops, orc = _ops(), _orc()
+    a = _randn(M, K, seed=16); w = _randn(N, K, seed=17, scale=0.05); b = _randn(N, seed=18)
+    c = ops.gemm_nt(a.to(DEV), w.to(DEV), b.to(DEV))
+    ref = orc.linear(a, w, b, orc.bf16_round)
+    assert rel_l2(c, ref) < 2e-3
+    c32 = ops.gemm_nt(a.to(DEV), w.to(DEV), b.to(DEV), out_f32=True)
+    assert rel_l2(c32, orc.linear(a, w, b)) < 1e-5
+
+
+def test_gemm_nt_lora_and_epilogues():
+    ops, orc = _ops(), _orc()
+    from lcv_hip.lib import LCV_EPI_GATE_RESIDUAL, LCV_EPI_GELU_TANH, LCV_EPI_SWIGLU
+    import torch.nn.functional as F
+    M, N, K, R = 330, 256, 256, 8
+    a = _randn(M, K, seed=19); w = _randn(N, K, seed=20, scale=0.05); b = _randn(N, seed=21)
+    A = _randn(R, K, seed=22, scale=0.05); Bu = _randn(N, R, seed=23, scale=0.05)
+    s = 2.0
+    h = ops.lora_down(a.to(DEV), A.to(DEV), s)  # [M, 64]
+    href = s * orc.bf16_round(a.float() @ A.float().t())
+    assert rel_l2(h[:, :R], href) < 2e-3 and h[:, R:].abs().max().item() == 0
+    w2 = torch.zeros(N, 64, dtype=BF16); w2[:, :R] = Bu
+    c = ops.gemm_nt(a.to(DEV), w.to(DEV), b.to(DEV), a2=h, w2=w2.to(DEV))
+    ref = orc.bf16_round(a.float() @ w.float().t() + b.float() + h[:, :R].float().cpu() @ Bu.float().t())
+    assert rel_l2(c, ref) < 2e-3
+    # gelu-tanh epilogue
+    c = ops.gemm_nt(a.to(DEV), w.to(DEV), b.to(DEV), epilogue=LCV_EPI_GELU_TANH)
+    ref = orc.bf16_round(F.gelu(orc.linear(a, w, b, orc.bf16_round), approximate="tanh"))
+    assert rel_l2(c, ref) < 2e-3
+    # gate-residual epilogue (rows_per_frame = 110 -> 3 frames)
+    resid = _randn(M, N, seed=24); mod = _randn(1, 3, 6 * N, seed=25, dtype=torch.float32)
+    c = ops.gemm_nt(a.to(DEV), w.to(DEV), b.to(DEV), epilogue=LCV_EPI_GATE_RESIDUAL, resid=resid.to(DEV),
+                    mod=mod.to(DEV), gate_idx=5, rows_per_frame=110)
+    g = mod[0, :, 5 * N:6 * N].repeat_interleave(110, dim=0)
+    ref = orc.bf16_round(resid.float() + g * orc.linear(a, w, b, orc.bf16_round))
+    assert rel_l2(c, ref) < 2e-3
+    # SwiGLU epilogue with [32 gate | 32 up] interleaved weight rows
+    Fh = 128
+    w1 = _randn(Fh, K, seed=26, scale=0.05); w3 = _randn(Fh, K, seed=27, scale=0.05)
+    wi = torch.stack([w1.view(Fh // 32, 32, K), w3.view(Fh // 32, 32, K)], dim=1).reshape(2 * Fh, K).contiguous()
+    c = ops.gemm_nt(a.to(DEV), wi.to(DEV), None, epilogue=LCV_EPI_SWIGLU)
+    gte, up = orc.linear(a, w1, None, orc.bf16_round), orc.linear(a, w3, None, orc.bf16_round)
+    ref = orc.bf16_round(orc.bf16_round(F.silu(gte)) * up)
+    assert c.shape == (M, Fh) and rel_l2(c, ref) < 2e-3
+
+
+def test_linear_f32_smallm():
+    ops, orc = _ops(), _orc()
+    import torch.nn.functional as F
+    a = _randn(26, 512, seed=28, dtype=torch.float32); w = _randn(1536, 512, seed=29, scale=0.05); b = _randn(1536, seed=30)
+    out = ops.linear_f32_smallm(a.to(DEV), w.to(DEV), b.to(DEV), act_in=1)
+    ref = F.silu(a) @ w.float().t() + b.float()
+    assert rel_l2(out, ref) < 1e-5
+
+
+def test_patchify_unpatchify():
+    ops, orc = _ops(), _orc()
+    import torch.nn.functional as F
+    B, Cin, T, H, W, C = 2, 16, 3, 8, 12, 128
+    x = _randn(B, Cin, T, H, W, seed=31)
+    wt = _randn(C, Cin, 1, 2, 2, seed=32, scale=0.1); bias = _randn(C, seed=33)
+    tok = ops.patchify(x.to(DEV), 64)
+    y = ops.gemm_nt(tok.view(-1, 64), wt.view(C, 64).to(DEV), bias.to(DEV)).view(B, -1, C)
+    ref = orc.x_embedder({"x_embedder.proj.weight": wt, "x_embedder.proj.bias": bias}, x, (1, 2, 2), orc.bf16_round)
+    assert rel_l2(y, ref) < 2e-3
+    t = _randn(B, T * (H // 2) * (W // 2), 64, seed=34, dtype=torch.float32)
+    out = ops.unpatchify(t.to(DEV), 16, T, H, W)
+    assert torch.equal(out.cpu(), orc.unpatchify(t, T, H // 2, W // 2, (1, 2, 2), 16))
+
+
+def test_denoise_glue_and_loss_pieces():
+    ops = _ops()
+    B, n = 2, 5000
+    c = _randn(B, n, seed=35, dtype=torch.float32); u = _randn(B, n, seed=36, dtype=torch.float32)
+    x = _randn(B, n, seed=37, dtype=torch.float32)
+    xd = x.to(DEV).clone()
+    ops.cfg_euler_step(c.to(DEV), u.to(DEV), xd, 4.0, -0.02, negate=True, zero_star=True)
+    st = (c * u).sum(1, keepdim=True) / ((u * u).sum(1, keepdim=True) + 1e-8)
+    v = u * st + 4.0 * (c - u * st)
+    assert torch.allclose(xd.cpu(), x + (-0.02) * (-v), atol=1e-5, rtol=1e-5)
+    # fm_noise: bit-exact with torch's (1-s)*x0 + s*eps in fp32 then .to(bf16)
+    x0 = _randn(B, 16, 3, 4, 6, seed=38); eps = _randn(B, 16, 3, 4, 6, seed=39)
+    sig = torch.tensor([0.3171, 0.9012], dtype=torch.float32)
+    got = ops.fm_noise(x0.to(DEV), eps.to(DEV), sig.to(DEV))
+    se = sig.view(B, 1, 1, 1, 1)
+    assert torch.equal(got.cpu(), ((1.0 - se) * x0 + se * eps).to(BF16))
+    # fm_mse
+    pred = _randn(B, 16, 5, 4, 6, seed=40, dtype=torch.float32)
+    loss, dpred = ops.fm_mse(pred.to(DEV), eps.to(DEV), x0.to(DEV), 2)
+    tgt = (eps - x0).float()
+    ref = torch.nn.functional.mse_loss(pred[:, :, 2:], tgt)
+    assert abs(loss.item() - ref.item()) < 1e-5 * max(1.0, ref.item())
+    gref = torch.zeros_like(pred); gref[:, :, 2:] = 2 * (pred[:, :, 2:] - tgt) / tgt.numel()
+    assert torch.allclose(dpred.cpu(), gref, atol=1e-7, rtol=1e-5)
