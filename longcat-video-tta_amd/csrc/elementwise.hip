@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_fwd_kernel(
   const int64_t in_base = b * in_sb + n * in_sn;
   for (int h0 = 0; h0 < H; h0 += 16) {
     const int h = h0 + hl;
-    // H is a multiple of 16 (checked on the host), so all 16-lane groups stay active for the shuffles
+    if (h >= H) continue;  // whole 16-lane groups drop out together, so the in-group shuffles stay valid
     const int64_t off = (int64_t)h * 128 + sub * 8;
     if (q_in) norm_rope_vec(q_in + in_base + off, q_out + b * q_sb + n * q_sn + off, wqf, cs, do_rope, eps);
     if (k_in) norm_rope_vec(k_in + in_base + off, k_out + b * kv_sb + n * kv_sn + off, wkf, cs, do_rope, eps);
@@ -232,7 +232,7 @@ extern "C" int lcv_qknorm_rope_fwd(const void* q_in, const void* k_in, const voi
   LCV_CHECK_ARG((q_in || k_in) && wq && wk, "qknorm_rope_fwd: null pointer");
   LCV_CHECK_ARG(!q_in || q_out, "qknorm_rope_fwd: q_out missing");
   LCV_CHECK_ARG(!k_in || k_out, "qknorm_rope_fwd: k_out missing");
-  LCV_CHECK_ARG(H > 0 && H % 16 == 0, "qknorm_rope_fwd: H=%ld must be a multiple of 16", (long)H);
+  LCV_CHECK_ARG(H > 0, "qknorm_rope_fwd: H must be positive");
   LCV_CHECK_ARG(in_sn % 8 == 0 && q_sn % 8 == 0 && kv_sn % 8 == 0 && in_sb % 8 == 0 && q_sb % 8 == 0 && kv_sb % 8 == 0,
                 "qknorm_rope_fwd: strides must be multiples of 8 elements");
   if (B == 0 || N == 0) return LCV_OK;

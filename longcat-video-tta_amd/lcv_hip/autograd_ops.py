@@ -1,0 +1,399 @@
+"""Differentiable front-ends of the HIP ops.
+
+Each op runs the forward kernel directly when no gradient is needed (denoise path) and goes
+through a `torch.autograd.Function` whose backward is another HIP kernel when it is (TTA inner
+loop).  Frozen base weights never get a gradient (LoRA-only backward): `dx = dy @ W` uses a
+resident transposed copy of W so that forward and backward share the one NT GEMM kernel.
+"""
+from typing import List, Optional, Tuple
+
+import torch
+
+from . import ops
+from .lib import (LCV_EPI_GELU_TANH, LCV_EPI_NONE, LCV_EPI_SWIGLU, LcvError)
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+_EPI = {None: LCV_EPI_NONE, "gelu_tanh": LCV_EPI_GELU_TANH}
+
+
+def _needs_grad(*ts) -> bool:
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts)
+
+
+# --------------------------------------------------------------------------- transposed weights
+_WT_CACHE = {}
+
+
+def transposed_weight(w: torch.Tensor) -> torch.Tensor:
+    """Resident W^T ([in, out], contiguous) for dx = dy @ W; rebuilt if the weight is modified."""
+    key = w.data_ptr()
+    ent = _WT_CACHE.get(key)
+    if ent is None or ent[0] != w._version or ent[1].shape != (w.shape[1], w.shape[0]):
+        with torch.no_grad():
+            wt = w.detach().t().contiguous()
+        _WT_CACHE[key] = (w._version, wt)
+        return wt
+    return ent[1]
+
+
+def clear_weight_caches():
+    _WT_CACHE.clear()
+
+
+# --------------------------------------------------------------------------- linear
+class _LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, epi, out_f32):
+        ctx.save_for_backward(w)
+        ctx.out_f32 = out_f32
+        if epi != LCV_EPI_NONE:
+            raise LcvError("linear: fused activation epilogues have no backward (embedders are frozen inputs)")
+        return ops.gemm_nt(x, w, b, epilogue=epi, out_f32=out_f32)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (w,) = ctx.saved_tensors
+        if w.requires_grad:
+            raise LcvError("linear: weight gradients are out of scope (LoRA-only backward); freeze the base weight")
+        dyb = dy if dy.dtype == BF16 else dy.to(BF16)
+        N = w.shape[0]
+        if N % 64:
+            raise LcvError("linear backward: out_features must be a multiple of 64")
+        dx = ops.gemm_nt(dyb.contiguous(), transposed_weight(w), None)
+        return dx, None, None, None, None
+
+
+def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], epilogue: Optional[str] = None,
+           out_f32: bool = False) -> torch.Tensor:
+    x = x if x.dtype == BF16 else x.to(BF16)
+    if not x.is_contiguous():
+        x = x.contiguous()
+    epi = _EPI[epilogue]
+    if _needs_grad(x, w, b):
+        return _LinearFn.apply(x, w, b, epi, out_f32)
+    return ops.gemm_nt(x, w, b, epilogue=epi, out_f32=out_f32)
+
+
+class _LinearF32Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, w, b, act_in):
+        ctx.save_for_backward(a, w)
+        ctx.act_in = act_in
+        return ops.linear_f32_smallm(a, w, b, act_in)
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, w = ctx.saved_tensors
+        if w.requires_grad:
+            raise LcvError("linear_f32: weight gradients are out of scope")
+        da = ops.linear_f32_smallm_bwd(dy.contiguous(), w, a, ctx.act_in)
+        return da, None, None, None
+
+
+def linear_f32(a: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], act_in: int = 0) -> torch.Tensor:
+    if _needs_grad(a, w, b):
+        return _LinearF32Fn.apply(a.contiguous(), w, b, act_in)
+    return ops.linear_f32_smallm(a, w, b, act_in)
+
+
+# --------------------------------------------------------------------------- norms / residual
+class _AdaLNFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mod, shift_idx, scale_idx, T, eps):
+        ctx.save_for_backward(x, mod)
+        ctx.args = (shift_idx, scale_idx, T, eps)
+        return ops.adaln_modulate(x, mod, shift_idx, scale_idx, T, eps)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mod = ctx.saved_tensors
+        shift_idx, scale_idx, T, eps = ctx.args
+        dx, dmod = ops.adaln_modulate_bwd(x, mod, dy.contiguous(), shift_idx, scale_idx, T, eps,
+                                          need_dmod=ctx.needs_input_grad[1])
+        return dx, dmod, None, None, None, None
+
+
+def adaln_modulate(x, mod, shift_idx, scale_idx, T, eps=1e-6):
+    if _needs_grad(x, mod):
+        return _AdaLNFn.apply(x, mod, shift_idx, scale_idx, T, eps)
+    return ops.adaln_modulate(x, mod, shift_idx, scale_idx, T, eps)
+
+
+class _LayerNormAffineFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        ctx.save_for_backward(x, w)
+        ctx.eps = eps
+        return ops.layernorm_affine(x, w, b, eps)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dx, dw, db = ops.layernorm_affine_bwd(x, w, dy.contiguous(), ctx.eps,
+                                              need_dw=ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+        return dx, (dw.to(w.dtype) if dw is not None else None), (db.to(w.dtype) if db is not None else None), None
+
+
+def layernorm_affine(x, w, b, eps=1e-6):
+    if _needs_grad(x, w, b):
+        return _LayerNormAffineFn.apply(x, w, b, eps)
+    return ops.layernorm_affine(x, w, b, eps)
+
+
+class _GateResidualFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, mod, gate_idx, T):
+        ctx.save_for_backward(y, mod)
+        ctx.args = (gate_idx, T)
+        return ops.gate_residual(x, y, mod, gate_idx, T)
+
+    @staticmethod
+    def backward(ctx, dout):
+        y, mod = ctx.saved_tensors
+        gate_idx, T = ctx.args
+        dout = dout.contiguous()
+        if mod is None:
+            return dout, dout, None, None, None
+        dy, dmod = ops.gate_residual_bwd(y, mod, dout, gate_idx, T, need_dmod=ctx.needs_input_grad[2])
+        return dout, dy, dmod, None, None
+
+
+def gate_residual(x, y, mod, gate_idx, T):
+    if _needs_grad(x, y, mod):
+        return _GateResidualFn.apply(x, y, mod, gate_idx, T)
+    return ops.gate_residual(x, y, mod, gate_idx, T)
+
+
+class _PadFrontZeroFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.n = n
+        B, N, C = x.shape
+        out = x.new_zeros((B, N + n, C))
+        out[:, n:].copy_(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        return dout[:, ctx.n:].contiguous(), None
+
+
+def pad_front_zero(x: torch.Tensor, n: int) -> torch.Tensor:
+    """[B, N, C] -> [B, n + N, C] with n leading zero rows (memory movement only)."""
+    if _needs_grad(x):
+        return _PadFrontZeroFn.apply(x, n)
+    B, N, C = x.shape
+    out = x.new_zeros((B, N + n, C))
+    out[:, n:].copy_(x)
+    return out
+
+
+# --------------------------------------------------------------------------- attention
+def _attend_regions(q, k, v, scale, n_cond, need_lse):
+    """q,k,v [B,N,H,D] views; conditioning tokens attend conditioning tokens only."""
+    B, N, H, D = q.shape
+    o = torch.empty((B, N, H, D), dtype=BF16, device=q.device)
+    lses = []
+    if n_cond > 0:
+        _, l1 = ops.attention(q[:, :n_cond], k[:, :n_cond], v[:, :n_cond], scale, out=o[:, :n_cond], need_lse=need_lse)
+        lses.append(l1)
+        if N > n_cond:
+            _, l2 = ops.attention(q[:, n_cond:], k, v, scale, out=o[:, n_cond:], need_lse=need_lse)
+            lses.append(l2)
+    else:
+        _, l1 = ops.attention(q, k, v, scale, out=o, need_lse=need_lse)
+        lses.append(l1)
+    return o, lses
+
+
+class _SelfAttentionFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, wq, wk, cs, scale, n_cond, eps):
+        B, N, _, H, D = qkv.shape
+        qk = torch.empty((B, N, 2, H, D), dtype=BF16, device=qkv.device)  # roped q, k (qkv kept for the norm backward)
+        ops.qknorm_rope(qkv[:, :, 0], qkv[:, :, 1], None, qk[:, :, 0], qk[:, :, 1], None, wq, wk, cs, 0, eps)
+        o, lses = _attend_regions(qk[:, :, 0], qk[:, :, 1], qkv[:, :, 2], scale, n_cond, True)
+        ctx.save_for_backward(qkv, qk, o, wq, wk, cs, *lses)
+        ctx.args = (scale, n_cond, eps)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, qk, o, wq, wk, cs, *lses = ctx.saved_tensors
+        scale, n_cond, eps = ctx.args
+        if wq.requires_grad or wk.requires_grad:
+            raise LcvError("self_attention: q/k norm weight gradients are not implemented (qk_norm tuning is out of scope)")
+        B, N, _, H, D = qkv.shape
+        do = do.contiguous()
+        dqkv_r = torch.zeros((B, N, 3, H, D), dtype=BF16, device=qkv.device)  # grads w.r.t. roped q,k and v
+        q, k, v = qk[:, :, 0], qk[:, :, 1], qkv[:, :, 2]
+        dq, dk, dv = dqkv_r[:, :, 0], dqkv_r[:, :, 1], dqkv_r[:, :, 2]
+        if n_cond > 0:
+            ops.attention_bwd(q[:, :n_cond], k[:, :n_cond], v[:, :n_cond], o[:, :n_cond], do[:, :n_cond], lses[0],
+                              dq[:, :n_cond], dk[:, :n_cond], dv[:, :n_cond], scale, accumulate_kv=False)
+            if N > n_cond:
+                # noise queries see every key: dk/dv of the cond rows receive a second contribution
+                ops.attention_bwd(q[:, n_cond:], k, v, o[:, n_cond:], do[:, n_cond:], lses[1],
+                                  dq[:, n_cond:], dk, dv, scale, accumulate_kv=True)
+        else:
+            ops.attention_bwd(q, k, v, o, do, lses[0], dq, dk, dv, scale, accumulate_kv=False)
+        dqkv = torch.empty_like(qkv)
+        ops.qknorm_rope_bwd(qkv[:, :, 0], qkv[:, :, 1], dq, dk, dqkv[:, :, 0], dqkv[:, :, 1], wq, wk, cs, 0, eps)
+        dqkv[:, :, 2].copy_(dv)
+        return dqkv, None, None, None, None, None, None
+
+
+def self_attention(qkv, wq, wk, cs, scale, n_cond, eps, return_kv=False):
+    """qkv [B,N,3,H,D] (fresh GEMM output).  Returns (o [B,N,H,D], kv) where kv = (K roped, V) of the
+    sequence as [B,N,H,D] copies when requested (conditioning-token KV cache)."""
+    if _needs_grad(qkv, wq, wk):
+        if return_kv:
+            raise LcvError("self_attention: return_kv is an inference-only path")
+        return _SelfAttentionFn.apply(qkv, wq, wk, cs, scale, n_cond, eps), None
+    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    ops.qknorm_rope(q, k, None, q, k, None, wq, wk, cs, 0, eps)  # in place on the GEMM output
+    o, _ = _attend_regions(q, k, v, scale, n_cond, False)
+    kv = (k.contiguous(), v.contiguous()) if return_kv else None
+    return o, kv
+
+
+def cached_attention(qkv, k_c, v_c, wq, wk, cs, scale, eps):
+    """Noise-token queries against [cached cond K/V | fresh K/V]; inference only."""
+    if _needs_grad(qkv):
+        raise LcvError("cached_attention: the KV-cached step is an inference-only path")
+    B, N, _, H, D = qkv.shape
+    n_c = k_c.shape[1]
+    kbuf = torch.empty((B, n_c + N, H, D), dtype=BF16, device=qkv.device)
+    vbuf = torch.empty((B, n_c + N, H, D), dtype=BF16, device=qkv.device)
+    kbuf[:, :n_c].copy_(k_c if k_c.shape[0] == B else k_c.expand(B, -1, -1, -1))
+    vbuf[:, :n_c].copy_(v_c if v_c.shape[0] == B else v_c.expand(B, -1, -1, -1))
+    q = qkv[:, :, 0]
+    ops.qknorm_rope(q, qkv[:, :, 1], qkv[:, :, 2], q, kbuf[:, n_c:], vbuf[:, n_c:], wq, wk, cs, n_c, eps)
+    o, _ = ops.attention(q, kbuf, vbuf, scale)
+    return o
+
+
+class _CrossAttentionFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q_raw, kv_raw, wq, wk, seqlens, scale, eps):
+        B, N, H, D = q_raw.shape
+        L = kv_raw.shape[1]
+        qn = torch.empty_like(q_raw)
+        kn = torch.empty((1, L, H, D), dtype=BF16, device=q_raw.device)
+        ops.qknorm_rope(q_raw, None, None, qn, None, None, wq, wk, None, 0, eps)
+        ops.qknorm_rope(None, kv_raw[:, :, 0], None, None, kn, None, wq, wk, None, 0, eps)
+        o = torch.empty_like(q_raw)
+        lses, off = [], 0
+        for b in range(B):
+            Lb = int(seqlens[b])
+            _, l = ops.attention(qn[b:b + 1], kn[:, off:off + Lb], kv_raw[:, off:off + Lb, 1], scale, out=o[b:b + 1],
+                                 need_lse=True)
+            lses.append(l)
+            off += Lb
+        ctx.save_for_backward(q_raw, kv_raw, qn, kn, o, wq, wk, *lses)
+        ctx.args = (list(seqlens), scale, eps)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q_raw, kv_raw, qn, kn, o, wq, wk, *lses = ctx.saved_tensors
+        seqlens, scale, eps = ctx.args
+        if wq.requires_grad or wk.requires_grad:
+            raise LcvError("cross_attention: q/k norm weight gradients are not implemented")
+        B, N, H, D = q_raw.shape
+        L = kv_raw.shape[1]
+        do = do.contiguous()
+        dqn = torch.empty_like(qn)
+        dkv = torch.zeros((1, L, 2, H, D), dtype=BF16, device=q_raw.device)  # [dk (normed) | dv]
+        off = 0
+        for b in range(B):
+            Lb = int(seqlens[b])
+            ops.attention_bwd(qn[b:b + 1], kn[:, off:off + Lb], kv_raw[:, off:off + Lb, 1], o[b:b + 1], do[b:b + 1],
+                              lses[b], dqn[b:b + 1], dkv[:, off:off + Lb, 0], dkv[:, off:off + Lb, 1], scale,
+                              accumulate_kv=False)
+            off += Lb
+        dq_raw = torch.empty_like(q_raw)
+        ops.qknorm_rope_bwd(q_raw, None, dqn, None, dq_raw, None, wq, wk, None, 0, eps)
+        dkv_raw = torch.empty_like(kv_raw)
+        ops.qknorm_rope_bwd(None, kv_raw[:, :, 0], None, dkv[:, :, 0], None, dkv_raw[:, :, 0], wq, wk, None, 0, eps)
+        dkv_raw[:, :, 1].copy_(dkv[:, :, 1])
+        return dq_raw, dkv_raw, None, None, None, None, None
+
+
+def cross_attention(q, kv, wq, wk, seqlens: List[int], scale, eps):
+    """q [B,N,H,D] (fresh), kv [1, sum(seqlens), 2, H, D] (fresh) -> o [B,N,H,D]."""
+    if _needs_grad(q, kv, wq, wk):
+        return _CrossAttentionFn.apply(q, kv, wq, wk, seqlens, scale, eps)
+    B, N, H, D = q.shape
+    k, v = kv[:, :, 0], kv[:, :, 1]
+    ops.qknorm_rope(q, None, None, q, None, None, wq, wk, None, 0, eps)
+    ops.qknorm_rope(None, k, None, None, k, None, wq, wk, None, 0, eps)
+    o = torch.empty_like(q)
+    off = 0
+    for b in range(B):
+        Lb = int(seqlens[b])
+        ops.attention(q[b:b + 1], k[:, off:off + Lb], v[:, off:off + Lb], scale, out=o[b:b + 1])
+        off += Lb
+    return o
+
+
+# --------------------------------------------------------------------------- SwiGLU
+class _SwiGLUFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, g, u):
+        ctx.save_for_backward(g, u)
+        return ops.swiglu(g, u)
+
+    @staticmethod
+    def backward(ctx, dout):
+        g, u = ctx.saved_tensors
+        dg, du = ops.swiglu_bwd(g, u, dout.contiguous())
+        return dg, du
+
+
+def swiglu(g, u):
+    if _needs_grad(g, u):
+        return _SwiGLUFn.apply(g, u)
+    return ops.swiglu(g, u)
+
+
+def swiglu_fused(x2: torch.Tensor, w13: torch.Tensor) -> torch.Tensor:
+    """silu(x w1^T) * (x w3^T) in one GEMM (interleaved weight, epilogue in registers); inference only."""
+    return ops.gemm_nt(x2 if x2.is_contiguous() else x2.contiguous(), w13, None, epilogue=LCV_EPI_SWIGLU)
+
+
+# --------------------------------------------------------------------------- patch embed / unpatchify
+def patch_embed(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """x [B,Cin,T,H,W] -> [B, N, C]: patchify (k = c*4 + ph*2 + pw) + GEMM with the flattened conv weight."""
+    if _needs_grad(x, w, b):
+        raise LcvError("patch_embed: gradients w.r.t. the latent input or x_embedder are out of scope")
+    B = x.shape[0]
+    C = w.shape[0]
+    kin = w[0].numel()
+    kpad = ((kin + 63) // 64) * 64
+    w2 = w.reshape(C, kin)
+    if kpad != kin:
+        w2 = torch.nn.functional.pad(w2, (0, kpad - kin))
+    tok = ops.patchify(x if x.dtype == BF16 else x.to(BF16), kpad)
+    y = ops.gemm_nt(tok.view(-1, kpad), w2.contiguous(), b)
+    return y.view(B, -1, C)
+
+
+class _UnpatchifyFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tok, Cout, T, H, W):
+        ctx.args = (Cout, T, H, W, tok.dtype)
+        return ops.unpatchify(tok, Cout, T, H, W)
+
+    @staticmethod
+    def backward(ctx, dout):
+        Cout, T, H, W, dt = ctx.args
+        return ops.unpatchify_bwd(dout.contiguous(), Cout, T, H, W).to(dt), None, None, None, None
+
+
+def unpatchify(tok, Cout, T, H, W):
+    if _needs_grad(tok):
+        return _UnpatchifyFn.apply(tok, Cout, T, H, W)
+    return ops.unpatchify(tok, Cout, T, H, W)

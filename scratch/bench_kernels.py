@@ -1,0 +1,40 @@
+import sys, os, torch, time
+sys.path.insert(0, "longcat-video-tta_amd"); sys.path.insert(0, ".")
+from lcv_hip import ops
+from lcv_hip.lib import LCV_EPI_SWIGLU
+dev="cuda"; bf=torch.bfloat16
+def timeit(fn, n=5, warm=2):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize()
+    s=torch.cuda.Event(enable_timing=True); e=torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e)/n
+which = sys.argv[1] if len(sys.argv)>1 else "all"
+if which in ("all","attn"):
+    for N in (12480, 46800):
+        H=32; D=128
+        qkv=torch.randn(1,N,3,H,D,device=dev,dtype=bf)
+        o=torch.empty(1,N,H,D,device=dev,dtype=bf)
+        ms=timeit(lambda: ops.attention(qkv[:,:,0],qkv[:,:,1],qkv[:,:,2],D**-0.5,out=o), n=3, warm=1)
+        fl=4*N*N*H*D
+        print(f"attn N={N}: {ms:.2f} ms  {fl/ms/1e9:.1f} TF/s", flush=True)
+if which in ("all","gemm"):
+    for tile in ("1","2"):
+        os.environ["LCV_GEMM_TILE"]=tile
+    for (M,N,K,name) in ((46800,12288,4096,"qkv"),(46800,4096,4096,"proj"),(46800,22016,4096,"w13"),(46800,4096,11008,"w2")):
+        a=torch.randn(M,K,device=dev,dtype=bf); w=torch.randn(N,K,device=dev,dtype=bf)*0.02; b=torch.randn(N,device=dev,dtype=bf)
+        ms=timeit(lambda: ops.gemm_nt(a,w,b), n=5, warm=2)
+        print(f"gemm {name} M={M} N={N} K={K}: {ms:.2f} ms  {2*M*N*K/ms/1e9:.1f} TF/s", flush=True)
+        ms=timeit(lambda: torch.nn.functional.linear(a,w,b), n=5, warm=2)
+        print(f"   torch(hipblaslt) : {ms:.2f} ms  {2*M*N*K/ms/1e9:.1f} TF/s", flush=True)
+        del a,w
+if which in ("all","elem"):
+    N=46800; C=4096; T=13
+    x=torch.randn(1,N,C,device=dev,dtype=bf); mod=torch.randn(1,T,6*C,device=dev)
+    ms=timeit(lambda: ops.adaln_modulate(x,mod,0,1,T)); print(f"adaln: {ms:.3f} ms {2*N*C*2/ms/1e6:.0f} GB/s")
+    y=torch.randn_like(x)
+    ms=timeit(lambda: ops.gate_residual(x,y,mod,2,T)); print(f"gate_residual: {ms:.3f} ms {3*N*C*2/ms/1e6:.0f} GB/s")
+    qkv=torch.randn(1,N,3,32,128,device=dev,dtype=bf); w=torch.ones(128,device=dev,dtype=bf); cs=torch.randn(N,64,2,device=dev)
+    ms=timeit(lambda: ops.qknorm_rope(qkv[:,:,0],qkv[:,:,1],None,qkv[:,:,0],qkv[:,:,1],None,w,w,cs)); print(f"qknorm_rope: {ms:.3f} ms {4*N*C*2/ms/1e6:.0f} GB/s")
