@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""Headline benchmark: denoised latent frames / s on the 49x720p, 50-step, CFG denoise of the LongCat-Video DiT
+(13.6 B parameters, 48 blocks) — BASELINE.json's metric on workload K3 (latents [1,16,13,90,160], 46 800 tokens).
+
+A "step" is one denoise step of the hot path: a batched (uncond | cond) DiT forward over all tokens followed by the
+fused CFG-zero-star + Euler update.  `value` = T_lat / (num_inference_steps * seconds_per_step) = finished latent
+frames per second of the 50-step job, whole-job aggregate over ranks (data-parallel: one independent video per GPU,
+no data-path collective => "weak" scaling).  Inputs are resident in HBM before the timed region.
+
+Extra objects on the JSON line: `roofline` (flash-attention forward, the dominant kernel: algorithmic flops per launch
+/ its average launch duration measured with HIP events on the launch stream inside the timed region) and
+`cpu_baseline` (the CPU oracle timed on this box's host cores on a bounded sample; rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+for p in (str(ROOT), str(ROOT / "longcat-video-tta_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+WORKLOADS = {  # name: (T_lat, h, w, description)
+    "K1": (5, 32, 32, "16x256x256 clip (17 frames -> 5 latent frames, 1 280 tokens)"),
+    "K2": (13, 60, 104, "49x480p (13 latent frames, 20 280 tokens)"),
+    "K3": (13, 90, 160, "49x720p (13 latent frames, 46 800 tokens)"),
+}
+MFMA_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="K3", choices=sorted(WORKLOADS))
+    ap.add_argument("--num-inference-steps", type=int, default=50)
+    ap.add_argument("--guidance-scale", type=float, default=4.0)
+    ap.add_argument("--depth", type=int, default=48, help="debug only: anything but 48 is not the named model")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(num_inference_steps: int) -> dict:
+    """Time the CPU oracle (oracle/dit_oracle.py, kind 'port') on the reference's CPU-runnable case K1 at full width,
+    depth 2, and extrapolate linearly to 48 blocks (embedders/head are <0.5 % and ignored)."""
+    from oracle import dit_oracle as orc
+    # a one-GPU box gives this job a 16-core CPU share; more threads than that only oversubscribe
+    cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
+    torch.set_num_threads(cores)
+    cfg = dict(hidden_size=4096, depth=2, num_heads=32, in_channels=16, out_channels=16, adaln_tembed_dim=512,
+               caption_channels=4096, patch_size=(1, 2, 2), ffn_hidden=orc.ffn_hidden_dim(4096),
+               frequency_embedding_size=256, text_tokens_zero_pad=False)
+    P = {k: v.float() for k, v in orc.make_params(cfg, seed=1234).items()}  # bf16-valued weights, widened once
+    T, h, w, _ = WORKLOADS["K1"]
+    g = torch.Generator().manual_seed(42)
+    x = torch.randn(1, 16, T, h, w, generator=g).to(torch.bfloat16)
+    y = torch.randn(1, 1, 512, 4096, generator=g).to(torch.bfloat16)
+    mask = torch.zeros(1, 512, dtype=torch.int64)
+    mask[:, :77] = 1
+    ts = torch.full((1, T), 500.0).to(torch.bfloat16)
+    N_t, N_h, N_w = T, h // 2, w // 2
+    rnd = orc.bf16_round
+    with torch.no_grad():
+        xe = orc.x_embedder(P, x.float(), (1, 2, 2), rnd)
+        t = orc.t_embedder(P, ts.float().flatten()).reshape(1, N_t, -1)
+        ye, lens = orc.pack_text(orc.y_embedder(P, y.float(), rnd), mask)
+        times = []
+        for it in range(3):
+            t0 = time.perf_counter()
+            out = xe
+            for i in range(2):
+                out = orc.block_forward(P, f"blocks.{i}.", out, ye, t, lens, (N_t, N_h, N_w), 0, 32, rnd)
+            times.append(time.perf_counter() - t0)
+            if sum(times) > 30.0:
+                break
+    per_block = min(times[1:] or times) / 2
+    fwd48 = per_block * 48
+    sec_per_step = 2 * fwd48  # CFG: two forwards per step
+    return {"value": T / (num_inference_steps * sec_per_step), "unit": "denoised latent frames/s", "cores": cores,
+            "kind": "port",
+            "sample": f"K1 {WORKLOADS['K1'][3]}: 2 of 48 blocks at full width timed (best of {max(len(times) - 1, 1)} after warm-up, "
+                      f"{per_block:.2f} s/block), linear extrapolation to 48 blocks x 2 CFG forwards; fp32 math at "
+                      "the bf16 rounding points"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl")
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+
+    cpu_base = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_base = cpu_baseline(args.num_inference_steps)
+
+    from lcv_hip import lib, ops
+    lib.call("lcv_device_check")
+    from longcat_video.modules.longcat_video_dit import LongCatVideoTransformer3DModel
+    from longcat_video.modules.scheduling_flow_match_euler_discrete import FlowMatchEulerDiscreteScheduler
+    from longcat_video.pipeline_longcat_video import LongCatVideoPipeline
+
+    T, h, w, desc = WORKLOADS[args.workload]
+    dit = LongCatVideoTransformer3DModel(device=dev, dtype=torch.bfloat16, depth=args.depth).eval()
+    dit.init_synthetic_(seed=1234)
+    pipe = LongCatVideoPipeline(scheduler=FlowMatchEulerDiscreteScheduler(), dit=dit)
+    pipe.device = dev
+
+    # synthetic inputs: one independent video per rank (data parallel), seeded per rank
+    g = torch.Generator(device=dev).manual_seed(42 + rank)
+    latents = torch.randn((1, 16, T, h, w), generator=g, device=dev, dtype=torch.float32)
+    g2 = torch.Generator(device=dev).manual_seed(43)
+    pe = torch.randn((1, 1, 512, 4096), generator=g2, device=dev, dtype=torch.float32).to(torch.bfloat16)
+    ne = torch.randn((1, 1, 512, 4096), generator=g2, device=dev, dtype=torch.float32).to(torch.bfloat16)
+    pm = torch.zeros((1, 512), dtype=torch.int64, device=dev)
+    pm[:, :77] = 1
+    nm = torch.zeros((1, 512), dtype=torch.int64, device=dev)
+    nm[:, :77] = 1
+
+    def run(start, stop, x):
+        return pipe.denoise(x, pe, pm, ne, nm, num_cond_latents=0, num_inference_steps=args.num_inference_steps,
+                            guidance_scale=args.guidance_scale, start_step=start, stop_step=stop)
+
+    x = latents
+    x = run(0, args.warmup, x)  # W untimed warm-up steps (also builds the fused-weight copies)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ops.PROFILE = []  # (start_event, end_event, flops) per attention launch, recorded on the launch stream
+    t0 = time.perf_counter()
+    x = run(args.warmup, args.warmup + args.steps, x)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    prof, ops.PROFILE = ops.PROFILE, None
+    if dist is not None:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = tmax.item()
+    assert torch.isfinite(x).all().item(), "non-finite latents"
+
+    sec_per_step = elapsed / args.steps
+    per_gpu = T / (args.num_inference_steps * sec_per_step)
+    value = per_gpu * world
+
+    # roofline of the dominant kernel (self-attention forward launches only: Nq = Nk = all tokens)
+    big = [(s.elapsed_time(e), f) for (s, e, f, nq, nk) in prof if nq == nk]
+    avg_ms = sum(m for m, _ in big) / max(len(big), 1)
+    flops = big[0][1] if big else 0.0
+    achieved = flops / (avg_ms * 1e-3) / 1e12 if big else 0.0
+    traffic = None
+    pmc = ROOT / "profiles" / "attn_fwd_hbm_traffic.json"
+    if pmc.exists():
+        try:
+            traffic = json.loads(pmc.read_text()).get(args.workload)
+        except Exception:
+            traffic = None
+    line = {
+        "metric": "denoised latent frames/sec (49x720p, 50-step CFG denoise)", "value": value,
+        "unit": "latent frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": sec_per_step * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"{args.workload}: {desc}; DiT 48 blocks x 4096 hidden, CFG {args.guidance_scale}, "
+                               f"{args.num_inference_steps}-step flow-match Euler, no conditioning frames",
+                   "depth": args.depth, "tokens": T * (h // 2) * (w // 2), "parallelism": f"dp{world}",
+                   "latent_frame_steps_per_s": T * world / sec_per_step,
+                   "wall_clock_per_video_s_extrapolated": sec_per_step * args.num_inference_steps},
+        "roofline": {"kernel": "attn_fwd_kernel<8>", "bound": "mfma", "achieved": achieved, "peak": MFMA_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": traffic,
+                     "avg_launch_ms": avg_ms, "launches": len(big), "flops_per_launch": flops},
+    }
+    if cpu_base is not None:
+        line["cpu_baseline"] = cpu_base
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

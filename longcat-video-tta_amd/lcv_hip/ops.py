@@ -14,6 +14,7 @@ from .lib import (LCV_EPI_GATE_RESIDUAL, LCV_EPI_GELU_TANH, LCV_EPI_NONE, LCV_EP
 
 BF16 = torch.bfloat16
 F32 = torch.float32
+PROFILE = None  # set to a list by bench.py to collect (start, end, flops, Nq, Nk) per attention launch
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -119,10 +120,16 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float,
     if out is None:
         out = torch.empty((B, Nq, H, D), dtype=BF16, device=q.device)
     lse = torch.empty((B, H, Nq), dtype=F32, device=q.device) if need_lse else None
+    if PROFILE is not None:  # bench.py: HIP events on the launch stream around the dominant kernel
+        ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
+        ev0.record()
     call("lcv_attn_fwd", _ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), B, H, Nq, Nk,
          q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2),
          v.stride(0), v.stride(1), v.stride(2), out.stride(0), out.stride(1), out.stride(2),
          float(scale), _stream())
+    if PROFILE is not None:
+        ev1.record()
+        PROFILE.append((ev0, ev1, 4.0 * B * H * Nq * Nk * D, Nq, Nk))
     return out, lse
 
 
