@@ -98,13 +98,12 @@ int lcv_qknorm_rope_fwd(const void* q_in, const void* k_in, const void* v_in,
                         int64_t kv_sb, int64_t kv_sn,       /* k_out/v_out strides */
                         int64_t pos_off, float eps, void* stream);
 /* Backward: given dq_out, dk_out (same addressing as q_out/k_out) and the
- * pre-norm q_in/k_in, writes dq_in, dk_in (addressing of q_in) ; dwq/dwk fp32 [D]
- * accumulated when non-NULL. */
+ * pre-norm q_in/k_in, writes dq_in, dk_in (strides din_*).  The norm weights are
+ * frozen on this path (qk_norm tuning is out of scope). */
 int lcv_qknorm_rope_bwd(const void* q_in, const void* k_in,
                         const void* dq_out, const void* dk_out,
                         void* dq_in, void* dk_in,
                         const void* wq, const void* wk, const void* cs,
-                        float* dwq, float* dwk,
                         int64_t B, int64_t N, int64_t H,
                         int64_t in_sb, int64_t in_sn,
                         int64_t q_sb, int64_t q_sn,
@@ -127,12 +126,13 @@ int lcv_attn_fwd(const void* q, const void* k, const void* v, void* o, float* ls
                  int64_t v_sb, int64_t v_sn, int64_t v_sh,
                  int64_t o_sb, int64_t o_sn, int64_t o_sh,
                  float scale, void* stream);
-/* Backward. delta_ws: fp32 workspace [B,H,Nq]; dq_acc: fp32 workspace
- * [B,Nq,H,128] zero-filled by the callee; dq/dk/dv addressed like q/k/v. */
+/* Backward (two passes, no atomics: dK/dV per 128-key workgroup, dQ per 256-query workgroup; see csrc/attn_bwd.hip).
+ * d_o shares o's strides.  delta_ws: fp32 workspace [B,H,Nq].  accumulate_kv != 0 adds into the existing dk/dv
+ * (second region of the conditioning split).  dq/dk/dv are addressed like q/k/v with their own strides. */
 int lcv_attn_bwd(const void* q, const void* k, const void* v, const void* o,
                  const void* d_o, const float* lse,
                  void* dq, void* dk, void* dv,
-                 float* delta_ws, float* dq_acc,
+                 float* delta_ws, int accumulate_kv,
                  int64_t B, int64_t H, int64_t Nq, int64_t Nk,
                  int64_t q_sb, int64_t q_sn, int64_t q_sh,
                  int64_t k_sb, int64_t k_sn, int64_t k_sh,
@@ -167,15 +167,21 @@ int lcv_gemm_nt(const void* a, const void* w, const void* bias,
  * (lora_down of LoRALinear, run_lora_tta.py:247-260). */
 int lcv_lora_down(const void* x, const void* A, void* h, int64_t M, int64_t K, int64_t R,
                   int64_t Rpad, int64_t ldx, float s, void* stream);
-/* LoRA-only backward pieces (no dW of the frozen base weight):
- *   dB[N,R] (+)= dy[M,N]^T @ h[M,R]      (h = bf16(x A^T), unscaled; result scaled by s)
- *   g[M,R]   =  s * dy[M,N] @ B[N,R]
- *   dA[R,K] (+)= g[M,R]^T @ x[M,K]
- * fp32 outputs, accumulated over row chunks by atomics; caller zero-fills. */
-int lcv_lora_bwd_dB_g(const void* dy, const void* h, const void* Bw, float* dB, void* g,
-                      int64_t M, int64_t N, int64_t R, int64_t Rpad, int64_t lddy, float s, void* stream);
-int lcv_lora_bwd_dA(const void* g, const void* x, float* dA,
-                    int64_t M, int64_t K, int64_t R, int64_t Rpad, int64_t ldx, void* stream);
+/* LoRA-only backward (no dW of the frozen base weight), with h = bf16(x A^T), g = s * dy B (= lcv_lora_down(dy, B^T)):
+ *   dx = dy W + g A            -> lcv_gemm_nt(dy, W^T, a2 = g, w2 = A^T)
+ *   dA[R,K]   = g^T x          -> lcv_tn_skinny(g, x)
+ *   dB^T[R,N] = s * h^T dy     -> lcv_tn_skinny(h, dy, scale = s)
+ * out[r,k] += scale * sum_m g[m,r] x[m,k]; g: [M,Rpad] bf16, x: [M,K] bf16 (row stride ldx), out: [R,K] fp32,
+ * accumulated with fp32 atomics (caller zero-fills). */
+int lcv_tn_skinny(const void* g, const void* x, float* out, int64_t M, int64_t K, int64_t R, int64_t Rpad,
+                  int64_t ldx, float scale, void* stream);
+/* fp32 islands (t_embedder MLP, adaLN_modulation under the upstream fp32 autocast; run_delta_a.py:161-165):
+ * out[M,N] fp32 = act_in(a[M,K] fp32) @ w[N,K]^T (bf16 weights widened) + bias;  act_in: 0 none, 1 SiLU. */
+int lcv_linear_f32_smallm(const float* a, const void* w, const void* bias, float* out, int64_t M, int64_t N,
+                          int64_t K, int act_in, void* stream);
+/* da[M,K] fp32 = act_in'(a) * (dy[M,N] @ w[N,K])  (gradient towards the timestep embedding: delta-A/B TTA). */
+int lcv_linear_f32_smallm_bwd(const float* dy, const void* w, const float* a, float* da, int64_t M, int64_t N,
+                              int64_t K, int act_in, void* stream);
 
 /* ---- SwiGLU --------------------------------------------------------- */
 int lcv_swiglu_fwd(const void* gate, const void* up, void* out, int64_t rows, int64_t F,
@@ -192,6 +198,9 @@ int lcv_patchify(const void* x, void* tok, int64_t B, int64_t Cin, int64_t T, in
  * (upstream unpatchify; delta_experiment/scripts/run_delta_a.py:213-217). */
 int lcv_unpatchify(const void* tok, float* out, int64_t B, int64_t Cout, int64_t T, int64_t H, int64_t W,
                    int tok_is_f32, void* stream);
+/* dtok [B, N, 4*Cout] fp32 <- dout [B,Cout,T,H,W] fp32. */
+int lcv_unpatchify_bwd(const float* dout, float* dtok, int64_t B, int64_t Cout, int64_t T, int64_t H, int64_t W,
+                       void* stream);
 
 /* ---- denoise step glue ---------------------------------------------- */
 /* CFG-zero-star combine + sign + Euler update, fp32:
@@ -216,37 +225,26 @@ int lcv_fm_mse(const float* pred, const void* eps, const void* x0, float* loss_o
                int64_t B, int64_t C, int64_t T, int64_t Tc, int64_t HW, void* stream);
 
 /* ---- fused multi-tensor AdamW + global-norm clip --------------------- */
-/* One descriptor per parameter tensor (device array of structs). */
+/* One descriptor per parameter tensor (device array).  Tensors are cut into 2048-element chunks; a tensor's
+ * chunks are [first_chunk, first_chunk + ceil(numel/2048)). */
 typedef struct {
   void* param;      /* bf16 or fp32 (see param_f32) */
   void* grad;       /* same dtype as param */
   void* exp_avg;    /* same dtype as param */
   void* exp_avg_sq; /* same dtype as param */
   int64_t numel;
+  int64_t first_chunk;
 } lcv_adam_tensor;
-/* sum of squares of all grads -> norm_sq[0] (fp32, zero-filled by callee). */
-int lcv_grad_norm_sq(const lcv_adam_tensor* tensors, int64_t n_tensors, int param_f32,
-                     float* norm_sq, void* stream);
-/* torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW.step (decoupled weight decay,
- * bias correction, eps outside sqrt/bias2) in one launch; reads norm_sq[0].
- * lora_experiment/scripts/run_lora_tta.py:462-468, 513-514. */
-int lcv_adamw_clip_step(const lcv_adam_tensor* tensors, int64_t n_tensors, int param_f32,
-                        const float* norm_sq, float max_norm, float lr, float beta1, float beta2,
-                        float eps, float weight_decay, int64_t step, void* stream);
-
-/* ---- VAE decoder stages (WAN-style causal 3-D conv VAE) -------------- */
-/* Causal conv3d, channels-last activations [B, T, H, W, Cin] bf16, weight
- * [Cout, kt, kh, kw, Cin] bf16, bias [Cout]; temporal padding is causal
- * (kt-1 frames in front, taken from `cache` [B, kt-1, H, W, Cin] when non-NULL,
- * zeros otherwise), spatial padding (kh/2, kw/2) zeros.  out [B,T,H,W,Cout]. */
-int lcv_causal_conv3d(const void* x, const void* cache, const void* w, const void* bias, void* out,
-                      int64_t B, int64_t T, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
-                      int kt, int kh, int kw, void* stream);
-/* WAN RMS_norm over channels (channels-last): y = x / max(||x||_2,eps) * sqrt(C) * gamma[c], then optional SiLU. */
-int lcv_vae_rmsnorm_silu(const void* x, const void* gamma, void* y, int64_t rows, int64_t C,
-                         int apply_silu, void* stream);
-/* nearest-exact 2x spatial upsample, channels-last. */
-int lcv_upsample2x(const void* x, void* y, int64_t BT, int64_t H, int64_t W, int64_t C, void* stream);
+/* torch.nn.utils.clip_grad_norm_: per-tensor norms (rounded to the grad dtype) -> total norm -> coefficient
+ * min(max_norm / (total + 1e-6), 1).  per_tensor_ws: fp32 [n_tensors]; norm_coef_out: fp32 [2] = {norm, coef}.
+ * lora_experiment/scripts/run_lora_tta.py:513. */
+int lcv_grad_norm_clip(const lcv_adam_tensor* tensors, int64_t n_tensors, int64_t total_chunks, int param_f32,
+                       float max_norm, float* per_tensor_ws, float* norm_coef_out, void* stream);
+/* torch.optim.AdamW(foreach).step in one launch, with the bf16 rounding points of the foreach op sequence;
+ * applies norm_coef[1] to the gradients on the fly when norm_coef != NULL.  run_lora_tta.py:462-468, 514. */
+int lcv_adamw_step(const lcv_adam_tensor* tensors, int64_t n_tensors, int64_t total_chunks, int param_f32,
+                   const float* norm_coef, double lr, double beta1, double beta2, double eps, double weight_decay,
+                   int64_t step, void* stream);
 
 #ifdef __cplusplus
 }

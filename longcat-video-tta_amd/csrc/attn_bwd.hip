@@ -1,0 +1,481 @@
+// Flash attention backward for the TTA inner loop (dense, non-causal, D = 128, bf16, fp32 accumulate).
+//
+// Two passes, no atomics, bitwise reproducible:
+//   pass A (attn_bwd_dkv_kernel): one workgroup = 4 waves = 128 keys of one (batch, head); each wave keeps
+//          dK^T and dV^T of its 32 keys in 128 accumulator registers while the workgroup sweeps 32-row
+//          query tiles (Q and dO staged in LDS, double-buffered).  S = Q K^T and dP = dO V^T are computed
+//          with the KEY ON THE LANE (K, V rows live in registers as B operands), so the exponentiated /
+//          differentiated tiles are already the B operands of dV^T += dO^T P and dK^T += Q^T dS.
+//   pass B (attn_bwd_dq_kernel): the forward kernel's geometry (8 waves x 32 query rows, 64-key tiles in LDS):
+//          S^T = K Q^T and dP^T = V dO^T with the QUERY on the lane (lse / delta are lane-local scalars),
+//          dQ^T += K^T dS^T with K^T fragments from ds_read_b64_tr_b16 on the same swizzled K image.
+//   delta = rowsum(dO * O) comes from a small HBM-bound pre-pass.
+// Recomputing S and dP in both passes costs 7 MFMA products instead of 5 (1.4x flops) and removes the dQ
+// accumulation across workgroups (float atomics run at ~1.3 TB/s chip-wide and would cap a 128-key-block
+// design near 0.4 PFLOP/s — MI355X_MICROARCH.md, Global float atomics).
+// Algorithmic work: 10*Nq*Nk*128 flop per (b, h); bytes (8*N*128*2 + 2*N*4) per (b, h).
+#include "lcv_common.h"
+
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+#define AS3 __attribute__((address_space(3)))
+
+struct AttnBwdParams {
+  const bf16_t* q;
+  const bf16_t* k;
+  const bf16_t* v;
+  const bf16_t* d_o;
+  const float* lse;
+  const float* delta;
+  bf16_t* dq;
+  bf16_t* dk;
+  bf16_t* dv;
+  int64_t Nq, Nk;
+  int H;
+  int64_t q_sb, q_sn, q_sh, k_sb, k_sn, k_sh, v_sb, v_sn, v_sh, o_sb, o_sn, o_sh;
+  int64_t dq_sb, dq_sn, dq_sh, dk_sb, dk_sn, dk_sh, dv_sb, dv_sn, dv_sh;
+  float scale, scale_log2e;
+  int accumulate_kv;
+};
+
+__device__ __forceinline__ int tile_off_b(int row, int ch) {
+  return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+}
+
+// ---------------------------------------------------------------------------
+// delta[b,h,q] = sum_d dO[b,q,h,d] * O[b,q,h,d]   (16 lanes per (q,h) row)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_bwd_delta_kernel(const bf16_t* __restrict__ o,
+                                                             const bf16_t* __restrict__ d_o,
+                                                             float* __restrict__ delta, int64_t Nq, int H,
+                                                             int64_t o_sb, int64_t o_sn, int64_t o_sh,
+                                                             int64_t do_sb, int64_t do_sn, int64_t do_sh) {
+  const int64_t b = blockIdx.z;
+  const int sub = threadIdx.x & 15;
+  const int64_t rowid = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);  // (q, h) pairs, h fastest
+  const int64_t total = Nq * H;
+  float acc = 0.f;
+  int64_t qi = 0;
+  int hh = 0;
+  const bool valid = rowid < total;
+  if (valid) {
+    qi = rowid / H;
+    hh = (int)(rowid - qi * H);
+    float a[8], c[8];
+    unpack8(*reinterpret_cast<const u16x8*>(o + b * o_sb + qi * o_sn + (int64_t)hh * o_sh + sub * 8), a);
+    unpack8(*reinterpret_cast<const u16x8*>(d_o + b * do_sb + qi * do_sn + (int64_t)hh * do_sh + sub * 8), c);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc += a[i] * c[i];
+  }
+  acc += __shfl_xor(acc, 8, 64);
+  acc += __shfl_xor(acc, 4, 64);
+  acc += __shfl_xor(acc, 2, 64);
+  acc += __shfl_xor(acc, 1, 64);
+  if (valid && sub == 0) delta[(b * H + hh) * Nq + qi] = acc;
+}
+
+// ---------------------------------------------------------------------------
+// pass A: dK, dV
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdParams p) {
+  constexpr int QT = 32;               // query rows per tile
+  constexpr int TILE_BYTES = QT * 256;  // one [32][128] bf16 tile
+  constexpr int STAGE = 2 * TILE_BYTES + 2 * QT * 4;  // Q | dO | lse | delta
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  lds_u8* lds = (lds_u8*)smem;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int head = blockIdx.y;
+  const int64_t b = blockIdx.z;
+  const int64_t key0 = (int64_t)blockIdx.x * 128 + wave * 32;
+
+  // ---- K, V rows of this lane's key as B operands: lane holds X[key0 + r][16*ks + 8*h .. +8] ----
+  bf16x8 kf[8], vf[8];
+  {
+    int64_t krow = key0 + r;
+    if (krow > p.Nk - 1) krow = p.Nk - 1;
+    const bf16_t* kp = p.k + b * p.k_sb + krow * p.k_sn + (int64_t)head * p.k_sh + 8 * h;
+    const bf16_t* vp = p.v + b * p.v_sb + krow * p.v_sn + (int64_t)head * p.v_sh + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      kf[ks] = *reinterpret_cast<const bf16x8*>(kp + 16 * ks);
+      vf[ks] = *reinterpret_cast<const bf16x8*>(vp + 16 * ks);
+    }
+  }
+
+  // ---- staging: 512 chunks per tile, 256 threads -> 2 chunks of Q and 2 of dO each ----
+  const bf16_t* qbase = p.q + b * p.q_sb + (int64_t)head * p.q_sh;
+  const bf16_t* dobase = p.d_o + b * p.o_sb + (int64_t)head * p.o_sh;
+  const float* lsebase = p.lse + (b * p.H + head) * p.Nq;
+  const float* delbase = p.delta + (b * p.H + head) * p.Nq;
+  int st_off[2], st_row[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = tid + i * 256;
+    st_row[i] = c >> 4;
+    st_off[i] = tile_off_b(c >> 4, c & 15);
+  }
+  const int st_col = (tid & 15) * 8;
+  u32x4 qreg[2], dreg[2];
+  float lreg = 0.f, dlreg = 0.f;
+  auto load_tile = [&](int64_t q0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int64_t row = q0 + st_row[i];
+      if (row > p.Nq - 1) row = p.Nq - 1;
+      qreg[i] = *reinterpret_cast<const u32x4*>(qbase + row * p.q_sn + st_col);
+      dreg[i] = *reinterpret_cast<const u32x4*>(dobase + row * p.o_sn + st_col);
+    }
+    if (tid < QT) {
+      const int64_t row = q0 + tid;
+      // rows past Nq get lse = +inf so that their P (and dS) are exactly zero
+      lreg = (row < p.Nq) ? lsebase[row] * 1.4426950408889634f : INFINITY;
+      dlreg = (row < p.Nq) ? delbase[row] : 0.f;
+    }
+  };
+  auto store_tile = [&](int buf) {
+    lds_u8* sb = lds + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      *reinterpret_cast<AS3 u32x4*>(sb + st_off[i]) = qreg[i];
+      *reinterpret_cast<AS3 u32x4*>(sb + TILE_BYTES + st_off[i]) = dreg[i];
+    }
+    if (tid < QT) {
+      *reinterpret_cast<AS3 float*>(sb + 2 * TILE_BYTES + tid * 4) = lreg;
+      *reinterpret_cast<AS3 float*>(sb + 2 * TILE_BYTES + QT * 4 + tid * 4) = dlreg;
+    }
+  };
+
+  // ---- LDS read addresses ----
+  const int rf = ((r & 3) << 2) | ((r >> 2) & 3);
+  const int row_off = 256 * r;
+  const int q4 = (lane >> 2) & 3, p4 = lane & 3, g1 = (lane >> 4) & 1;
+  int t_base[2], t_low[2];
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    t_base[half] = 256 * (4 * h + 8 * half + q4) + 8 * (p4 & 1);
+    t_low[half] = (2 * g1 + (p4 >> 1)) ^ (h + 2 * half);
+  }
+
+  f32x16 dkacc[4], dvacc[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { dkacc[d][e] = 0.f; dvacc[d][e] = 0.f; }
+
+  const int nt = (int)((p.Nq + QT - 1) / QT);
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  for (int t = 0; t < nt; ++t) {
+    const int buf = t & 1;
+    const bool has_next = (t + 1 < nt);
+    if (has_next) load_tile((int64_t)(t + 1) * QT);
+    const lds_u8* qb = lds + buf * STAGE;
+    const lds_u8* db = qb + TILE_BYTES;
+    const lds_u8* lb = qb + 2 * TILE_BYTES;
+
+    // ---- S = Q K^T, dP = dO V^T : rows = query (registers), cols = key (lane) ----
+    f32x16 s, dp;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const int co = 16 * ((2 * ks + h) ^ rf);
+      const bf16x8 aq = *reinterpret_cast<const AS3 bf16x8*>(qb + row_off + co);
+      const bf16x8 ad = *reinterpret_cast<const AS3 bf16x8*>(db + row_off + co);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, kf[ks], s, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad, vf[ks], dp, 0, 0, 0);
+    }
+    // ---- P = exp2(S*c - lse*log2e), dS = P * (dP - delta) * scale ----
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 l4 = *reinterpret_cast<const AS3 f32x4*>(lb + (8 * g + 4 * h) * 4);
+      const f32x4 d4 = *reinterpret_cast<const AS3 f32x4*>(lb + QT * 4 + (8 * g + 4 * h) * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float pv = __builtin_amdgcn_exp2f(s[4 * g + e] * p.scale_log2e - l4[e]);
+        s[4 * g + e] = pv;
+        dp[4 * g + e] = pv * (dp[4 * g + e] - d4[e]) * p.scale;
+      }
+    }
+    bf16x8 pb[2], dsb[2];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      pb[0][j] = (__bf16)s[j];
+      pb[1][j] = (__bf16)s[8 + j];
+      dsb[0][j] = (__bf16)dp[j];
+      dsb[1][j] = (__bf16)dp[8 + j];
+    }
+    // ---- dV^T += dO^T P ; dK^T += Q^T dS  (A operands by transposed reads of the dO / Q tiles) ----
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss) {
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const int dx = 64 * (d ^ q4);
+        const int a0 = t_base[0] + 4096 * ss + dx + 16 * t_low[0];
+        const int a1 = t_base[1] + 4096 * ss + dx + 16 * t_low[1];
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((AS3 s16x4*)(db + a0));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((AS3 s16x4*)(db + a1));
+        const bf16x8 dof = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        dvacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof, pb[ss], dvacc[d], 0, 0, 0);
+        const s16x4 lo2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((AS3 s16x4*)(qb + a0));
+        const s16x4 hi2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((AS3 s16x4*)(qb + a1));
+        const bf16x8 qtf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo2, hi2, 0, 1, 2, 3, 4, 5, 6, 7));
+        dkacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, dsb[ss], dkacc[d], 0, 0, 0);
+      }
+    }
+    if (has_next) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: acc[d][e] = dX^T[dim = 32*d + (e&3) + 8*(e>>2) + 4*h][key = lane & 31] ----
+  const int64_t krow = key0 + r;
+  if (krow < p.Nk) {
+    bf16_t* dkp = p.dk + b * p.dk_sb + krow * p.dk_sn + (int64_t)head * p.dk_sh;
+    bf16_t* dvp = p.dv + b * p.dv_sb + krow * p.dv_sn + (int64_t)head * p.dv_sh;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int col = 32 * d + 8 * i + 4 * h;
+        float kv4[4], vv4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { kv4[e] = dkacc[d][4 * i + e]; vv4[e] = dvacc[d][4 * i + e]; }
+        if (p.accumulate_kv) {
+          const u16x4 ok = *reinterpret_cast<const u16x4*>(dkp + col);
+          const u16x4 ov = *reinterpret_cast<const u16x4*>(dvp + col);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { kv4[e] += bf2f(ok[e]); vv4[e] += bf2f(ov[e]); }
+        }
+        u16x4 pk, pv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { pk[e] = f2bf(kv4[e]); pv[e] = f2bf(vv4[e]); }
+        *reinterpret_cast<u16x4*>(dkp + col) = pk;
+        *reinterpret_cast<u16x4*>(dvp + col) = pv;
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// pass B: dQ  (forward geometry)
+// ---------------------------------------------------------------------------
+template <int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void attn_bwd_dq_kernel(const AttnBwdParams p) {
+  constexpr int NT = NWAVES * 64;
+  constexpr int QROWS = NWAVES * 32;
+  constexpr int NCH = 1024 / NT;
+  constexpr int TILE_BYTES = 64 * 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  lds_u8* lds = (lds_u8*)smem;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int head = blockIdx.y;
+  const int64_t b = blockIdx.z;
+  const int64_t q0 = (int64_t)blockIdx.x * QROWS + wave * 32;
+  const bf16_t* kbase = p.k + b * p.k_sb + (int64_t)head * p.k_sh;
+  const bf16_t* vbase = p.v + b * p.v_sb + (int64_t)head * p.v_sh;
+
+  bf16x8 qf[8], dof[8];
+  float lse_q, delta_q;
+  {
+    int64_t qrow = q0 + r;
+    if (qrow > p.Nq - 1) qrow = p.Nq - 1;
+    const bf16_t* qp = p.q + b * p.q_sb + qrow * p.q_sn + (int64_t)head * p.q_sh + 8 * h;
+    const bf16_t* dp_ = p.d_o + b * p.o_sb + qrow * p.o_sn + (int64_t)head * p.o_sh + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      qf[ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
+      dof[ks] = *reinterpret_cast<const bf16x8*>(dp_ + 16 * ks);
+    }
+    lse_q = p.lse[(b * p.H + head) * p.Nq + qrow] * 1.4426950408889634f;
+    delta_q = p.delta[(b * p.H + head) * p.Nq + qrow];
+  }
+
+  int st_off[NCH], st_row[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = tid + i * NT;
+    st_row[i] = c >> 4;
+    st_off[i] = tile_off_b(c >> 4, c & 15);
+  }
+  const int st_col = (tid & 15) * 8;
+  u32x4 kreg[NCH], vreg[NCH];
+  auto load_tile = [&](int64_t kv0) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      int64_t row = kv0 + st_row[i];
+      if (row > p.Nk - 1) row = p.Nk - 1;
+      kreg[i] = *reinterpret_cast<const u32x4*>(kbase + row * p.k_sn + st_col);
+      vreg[i] = *reinterpret_cast<const u32x4*>(vbase + row * p.v_sn + st_col);
+    }
+  };
+  auto store_tile = [&](int buf) {
+    lds_u8* kb = lds + buf * 2 * TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      *reinterpret_cast<AS3 u32x4*>(kb + st_off[i]) = kreg[i];
+      *reinterpret_cast<AS3 u32x4*>(kb + TILE_BYTES + st_off[i]) = vreg[i];
+    }
+  };
+
+  const int kfz = ((r & 3) << 2) | ((r >> 2) & 3);
+  const int k_row_off = 256 * r;
+  const int q4 = (lane >> 2) & 3, p4 = lane & 3, g1 = (lane >> 4) & 1;
+  int t_base[2], t_low[2];
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    t_base[half] = 256 * (4 * h + 8 * half + q4) + 8 * (p4 & 1);
+    t_low[half] = (2 * g1 + (p4 >> 1)) ^ (h + 2 * half);
+  }
+
+  f32x16 dqacc[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dqacc[d][e] = 0.f;
+
+  const int nt = (int)((p.Nk + 63) / 64);
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    const int buf = t & 1;
+    const bool has_next = (t + 1 < nt);
+    if (has_next) load_tile((int64_t)(t + 1) * 64);
+    const lds_u8* kb = lds + buf * 2 * TILE_BYTES;
+    const lds_u8* vb = kb + TILE_BYTES;
+
+    f32x16 s0, s1, d0, d1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { s0[e] = 0.f; s1[e] = 0.f; d0[e] = 0.f; d1[e] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const int co = 16 * ((2 * ks + h) ^ kfz);
+      const bf16x8 a0 = *reinterpret_cast<const AS3 bf16x8*>(kb + k_row_off + co);
+      const bf16x8 a1 = *reinterpret_cast<const AS3 bf16x8*>(kb + 32 * 256 + k_row_off + co);
+      s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qf[ks], s0, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qf[ks], s1, 0, 0, 0);
+      const bf16x8 c0 = *reinterpret_cast<const AS3 bf16x8*>(vb + k_row_off + co);
+      const bf16x8 c1 = *reinterpret_cast<const AS3 bf16x8*>(vb + 32 * 256 + k_row_off + co);
+      d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c0, dof[ks], d0, 0, 0, 0);
+      d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c1, dof[ks], d1, 0, 0, 0);
+    }
+    if (!has_next && (p.Nk & 63)) {
+      const int valid = (int)(p.Nk - (int64_t)t * 64);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int key = (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (key >= valid) s0[e] = -INFINITY;
+        if (key + 32 >= valid) s1[e] = -INFINITY;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float p0 = __builtin_amdgcn_exp2f(s0[e] * p.scale_log2e - lse_q);
+      const float p1 = __builtin_amdgcn_exp2f(s1[e] * p.scale_log2e - lse_q);
+      s0[e] = p0 * (d0[e] - delta_q) * p.scale;
+      s1[e] = p1 * (d1[e] - delta_q) * p.scale;
+    }
+    bf16x8 dsb[4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      dsb[0][j] = (__bf16)s0[j];
+      dsb[1][j] = (__bf16)s0[8 + j];
+      dsb[2][j] = (__bf16)s1[j];
+      dsb[3][j] = (__bf16)s1[8 + j];
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const int dx = 64 * (d ^ q4);
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((AS3 s16x4*)(kb + t_base[0] + 4096 * kk + dx + 16 * t_low[0]));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((AS3 s16x4*)(kb + t_base[1] + 4096 * kk + dx + 16 * t_low[1]));
+        const bf16x8 ktf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        dqacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, dsb[kk], dqacc[d], 0, 0, 0);
+      }
+    }
+    if (has_next) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  const int64_t qrow = q0 + r;
+  if (qrow < p.Nq) {
+    bf16_t* dqp = p.dq + b * p.dq_sb + qrow * p.dq_sn + (int64_t)head * p.dq_sh;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        u16x4 pk;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pk[e] = f2bf(dqacc[d][4 * i + e]);
+        *reinterpret_cast<u16x4*>(dqp + 32 * d + 8 * i + 4 * h) = pk;
+      }
+  }
+}
+
+extern "C" int lcv_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o,
+                            const float* lse, void* dq, void* dk, void* dv, float* delta_ws, int accumulate_kv,
+                            int64_t B, int64_t H, int64_t Nq, int64_t Nk, int64_t q_sb, int64_t q_sn,
+                            int64_t q_sh, int64_t k_sb, int64_t k_sn, int64_t k_sh, int64_t v_sb, int64_t v_sn,
+                            int64_t v_sh, int64_t o_sb, int64_t o_sn, int64_t o_sh, int64_t dq_sb, int64_t dq_sn,
+                            int64_t dq_sh, int64_t dk_sb, int64_t dk_sn, int64_t dk_sh, int64_t dv_sb,
+                            int64_t dv_sn, int64_t dv_sh, float scale, void* stream) {
+  LCV_CHECK_ARG(q && k && v && o && d_o && lse && dq && dk && dv && delta_ws, "attn_bwd: null pointer");
+  LCV_CHECK_ARG(B > 0 && H > 0 && H <= 65535 && B <= 65535 && Nk > 0, "attn_bwd: bad sizes");
+  LCV_CHECK_ARG(q_sn % 8 == 0 && k_sn % 8 == 0 && v_sn % 8 == 0 && o_sn % 8 == 0 && q_sh % 8 == 0 && k_sh % 8 == 0 &&
+                    v_sh % 8 == 0 && o_sh % 8 == 0 && q_sb % 8 == 0 && k_sb % 8 == 0 && v_sb % 8 == 0 && o_sb % 8 == 0,
+                "attn_bwd: input strides must be multiples of 8 elements");
+  LCV_CHECK_ARG(dq_sn % 4 == 0 && dk_sn % 4 == 0 && dv_sn % 4 == 0 && dq_sh % 4 == 0 && dk_sh % 4 == 0 && dv_sh % 4 == 0 &&
+                    dq_sb % 4 == 0 && dk_sb % 4 == 0 && dv_sb % 4 == 0,
+                "attn_bwd: gradient strides must be multiples of 4 elements");
+  if (Nq == 0) return LCV_OK;
+  hipStream_t s = (hipStream_t)stream;
+  AttnBwdParams p;
+  p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.d_o = (const bf16_t*)d_o;
+  p.lse = lse; p.delta = delta_ws; p.dq = (bf16_t*)dq; p.dk = (bf16_t*)dk; p.dv = (bf16_t*)dv;
+  p.Nq = Nq; p.Nk = Nk; p.H = (int)H;
+  p.q_sb = q_sb; p.q_sn = q_sn; p.q_sh = q_sh; p.k_sb = k_sb; p.k_sn = k_sn; p.k_sh = k_sh;
+  p.v_sb = v_sb; p.v_sn = v_sn; p.v_sh = v_sh; p.o_sb = o_sb; p.o_sn = o_sn; p.o_sh = o_sh;
+  p.dq_sb = dq_sb; p.dq_sn = dq_sn; p.dq_sh = dq_sh; p.dk_sb = dk_sb; p.dk_sn = dk_sn; p.dk_sh = dk_sh;
+  p.dv_sb = dv_sb; p.dv_sn = dv_sn; p.dv_sh = dv_sh;
+  p.scale = scale; p.scale_log2e = scale * 1.4426950408889634f; p.accumulate_kv = accumulate_kv;
+
+  // delta pre-pass (dO shares o's strides by contract: both are [B,Nq,H,D] token-major tensors)
+  {
+    const int64_t rows = Nq * H;
+    hipLaunchKernelGGL(attn_bwd_delta_kernel, dim3((unsigned)((rows + 15) / 16), 1, (unsigned)B), dim3(256), 0, s,
+                       (const bf16_t*)o, (const bf16_t*)d_o, delta_ws, Nq, (int)H, o_sb, o_sn, o_sh, o_sb, o_sn, o_sh);
+    LCV_LAUNCH_CHECK("attn_bwd_delta");
+  }
+  {
+    const size_t lds = 2 * (2 * 32 * 256 + 2 * 32 * 4);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)((Nk + 127) / 128), (unsigned)H, (unsigned)B), dim3(256),
+                       lds, s, p);
+    LCV_LAUNCH_CHECK("attn_bwd_dkv");
+  }
+  {
+    constexpr int NW = 8;
+    const size_t lds = 2 * 2 * 64 * 256;
+    auto kern = attn_bwd_dq_kernel<NW>;
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        lcv_set_error("attn_bwd: cannot raise dynamic LDS");
+        return LCV_EDEVICE;
+      }
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)((Nq + NW * 32 - 1) / (NW * 32)), (unsigned)H, (unsigned)B),
+                       dim3(NW * 64), lds, s, p);
+    LCV_LAUNCH_CHECK("attn_bwd_dq");
+  }
+  return LCV_OK;
+}

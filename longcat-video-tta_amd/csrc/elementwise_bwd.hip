@@ -1,0 +1,485 @@
+// Backward kernels of the HBM-bound block pieces (TTA inner loop): AdaLN / LayerNorm, gated residual,
+// q/k RMSNorm + RoPE, SwiGLU, unpatchify, the fp32 small-M linear, and the skinny token contraction
+// that yields the LoRA dA / dB.  bf16 roundings of the forward are treated as identity (straight-through),
+// as autograd does for the reference's bf16 modules.
+#include "lcv_common.h"
+
+#define ROWNORM_MAXCH 8
+
+// ---------------------------------------------------------------------------
+// LayerNorm backward, one wave per row.
+//   MODE 0 (AdaLN): y = xh*(1+scale)+shift ; g = dy*(1+scale) ; dshift += dy ; dscale += dy*xh
+//   MODE 1 (affine): y = xh*w+b            ; g = dy*w         ; db += dy     ; dw += dy*xh
+//   dx = rstd * (g - mean(g) - xh * mean(g*xh))
+// ---------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void rownorm_bwd_kernel(
+    const bf16_t* __restrict__ x, const float* __restrict__ p_mul, const bf16_t* __restrict__ dy,
+    bf16_t* __restrict__ dx, float* __restrict__ d_add, float* __restrict__ d_mul, int64_t rows, int C,
+    int64_t S, int64_t mod_stride, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const bf16_t* xr = x + row * C;
+  const bf16_t* gr = dy + row * C;
+  const int64_t frame = (MODE == 0) ? row / S : 0;
+  const float* pm = p_mul + frame * mod_stride;
+  float v[ROWNORM_MAXCH][8], g[ROWNORM_MAXCH][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int ch = 0; ch < ROWNORM_MAXCH; ++ch) {
+    const int c = (ch * 64 + lane) * 8;
+    if (c < C) {
+      unpack8(*reinterpret_cast<const u16x8*>(xr + c), v[ch]);
+      unpack8(*reinterpret_cast<const u16x8*>(gr + c), g[ch]);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) sum += v[ch][i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { v[ch][i] = 0.f; g[ch][i] = 0.f; }
+    }
+  }
+  const float mean = wave_sum(sum) / (float)C;
+  float sq = 0.f;
+#pragma unroll
+  for (int ch = 0; ch < ROWNORM_MAXCH; ++ch) {
+    const int c = (ch * 64 + lane) * 8;
+    if (c < C) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float d = v[ch][i] - mean;
+        sq += d * d;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+  float sg = 0.f, sgx = 0.f;
+#pragma unroll
+  for (int ch = 0; ch < ROWNORM_MAXCH; ++ch) {
+    const int c = (ch * 64 + lane) * 8;
+    if (c < C) {
+      const f32x4 m0 = *reinterpret_cast<const f32x4*>(pm + c);
+      const f32x4 m1 = *reinterpret_cast<const f32x4*>(pm + c + 4);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float xh = (v[ch][i] - mean) * rstd;
+        const float dyv = g[ch][i];
+        if (d_add) {  // parameter / modulation gradients (fp32 atomics, 32-byte runs per lane)
+          atomicAdd(d_add + frame * mod_stride + c + i, dyv);
+          atomicAdd(d_mul + frame * mod_stride + c + i, dyv * xh);
+        }
+        const float mul = ((i < 4) ? m0[i] : m1[i - 4]) + ((MODE == 0) ? 1.0f : 0.0f);
+        const float gg = dyv * mul;
+        v[ch][i] = xh;
+        g[ch][i] = gg;
+        sg += gg;
+        sgx += gg * xh;
+      }
+    }
+  }
+  const float mg = wave_sum(sg) / (float)C;
+  const float mgx = wave_sum(sgx) / (float)C;
+  bf16_t* dr = dx + row * C;
+#pragma unroll
+  for (int ch = 0; ch < ROWNORM_MAXCH; ++ch) {
+    const int c = (ch * 64 + lane) * 8;
+    if (c < C) {
+      float o[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = rstd * (g[ch][i] - mg - v[ch][i] * mgx);
+      *reinterpret_cast<u16x8*>(dr + c) = pack8(o);
+    }
+  }
+}
+
+extern "C" int lcv_adaln_modulate_bwd(const void* x, const float* mod, const void* dy, void* dx, float* dmod,
+                                      int64_t B, int64_t T, int64_t S, int64_t C, int64_t mod_stride,
+                                      int64_t shift_off, int64_t scale_off, float eps, void* stream) {
+  LCV_CHECK_ARG(x && mod && dy && dx, "adaln_modulate_bwd: null pointer");
+  LCV_CHECK_ARG(C > 0 && C % 8 == 0 && C <= 4096, "adaln_modulate_bwd: C must be a multiple of 8 and <= 4096");
+  const int64_t rows = B * T * S;
+  if (rows == 0) return LCV_OK;
+  hipLaunchKernelGGL(rownorm_bwd_kernel<0>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, mod + scale_off, (const bf16_t*)dy, (bf16_t*)dx,
+                     dmod ? dmod + shift_off : nullptr, dmod ? dmod + scale_off : nullptr, rows, (int)C, S,
+                     mod_stride, eps);
+  LCV_LAUNCH_CHECK("adaln_modulate_bwd");
+  return LCV_OK;
+}
+
+extern "C" int lcv_layernorm_affine_bwd(const void* x, const float* w, const void* dy, void* dx, float* dw,
+                                        float* db, int64_t rows, int64_t C, float eps, void* stream) {
+  LCV_CHECK_ARG(x && w && dy && dx, "layernorm_affine_bwd: null pointer");
+  LCV_CHECK_ARG((dw == nullptr) == (db == nullptr), "layernorm_affine_bwd: dw and db go together");
+  LCV_CHECK_ARG(C > 0 && C % 8 == 0 && C <= 4096, "layernorm_affine_bwd: C must be a multiple of 8 and <= 4096");
+  if (rows == 0) return LCV_OK;
+  hipLaunchKernelGGL(rownorm_bwd_kernel<1>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, w, (const bf16_t*)dy, (bf16_t*)dx, db, dw, rows, (int)C, (int64_t)1,
+                     (int64_t)0, eps);
+  LCV_LAUNCH_CHECK("layernorm_affine_bwd");
+  return LCV_OK;
+}
+
+// ---------------------------------------------------------------------------
+// gated residual backward: dy = gate * dout ; dgate[frame] += dout * y
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gate_residual_bwd_kernel(const bf16_t* __restrict__ y,
+                                                                const float* __restrict__ gate,
+                                                                const bf16_t* __restrict__ dout,
+                                                                bf16_t* __restrict__ dy, float* __restrict__ dgate,
+                                                                int64_t n_packets, int cpk, int64_t S,
+                                                                int64_t mod_stride) {
+  for (int64_t pk = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; pk < n_packets;
+       pk += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = pk / cpk;
+    const int c = (int)(pk - row * cpk) * 8;
+    const int64_t goff = (row / S) * mod_stride + c;
+    float d[8], o[8];
+    unpack8(*reinterpret_cast<const u16x8*>(dout + pk * 8), d);
+    const f32x4 g0 = *reinterpret_cast<const f32x4*>(gate + goff);
+    const f32x4 g1 = *reinterpret_cast<const f32x4*>(gate + goff + 4);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = d[i] * ((i < 4) ? g0[i] : g1[i - 4]);
+    *reinterpret_cast<u16x8*>(dy + pk * 8) = pack8(o);
+    if (dgate) {
+      float yf[8];
+      unpack8(*reinterpret_cast<const u16x8*>(y + pk * 8), yf);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) atomicAdd(dgate + goff + i, d[i] * yf[i]);
+    }
+  }
+}
+
+extern "C" int lcv_gate_residual_bwd(const void* y, const float* mod, const void* dout, void* dy, float* dmod,
+                                     int64_t B, int64_t T, int64_t S, int64_t C, int64_t mod_stride,
+                                     int64_t gate_off, void* stream) {
+  LCV_CHECK_ARG(y && mod && dout && dy, "gate_residual_bwd: null pointer");
+  LCV_CHECK_ARG(C % 8 == 0 && gate_off % 4 == 0 && mod_stride % 4 == 0, "gate_residual_bwd: bad alignment");
+  const int64_t n_packets = B * T * S * (C / 8);
+  if (n_packets == 0) return LCV_OK;
+  int64_t blocks = (n_packets + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(gate_residual_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)y, mod + gate_off, (const bf16_t*)dout, (bf16_t*)dy,
+                     dmod ? dmod + gate_off : nullptr, n_packets, (int)(C / 8), S, mod_stride);
+  LCV_LAUNCH_CHECK("gate_residual_bwd");
+  return LCV_OK;
+}
+
+// ---------------------------------------------------------------------------
+// q/k RMSNorm + RoPE backward (weights frozen):  dx = r * (dn - n * mean(dn * n)),  dn = w * rope^T(dout)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void norm_rope_bwd_vec(const bf16_t* xin, const bf16_t* dout, bf16_t* dxin,
+                                                  const float (&w)[8], const float (&cs)[8], bool do_rope,
+                                                  float eps) {
+  float x[8], d[8];
+  unpack8(*reinterpret_cast<const u16x8*>(xin), x);
+  unpack8(*reinterpret_cast<const u16x8*>(dout), d);
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ss += x[i] * x[i];
+  ss += __shfl_xor(ss, 8, 64);
+  ss += __shfl_xor(ss, 4, 64);
+  ss += __shfl_xor(ss, 2, 64);
+  ss += __shfl_xor(ss, 1, 64);
+  const float r = rsqrtf(ss * (1.0f / 128.0f) + eps);
+  float dn[8], n[8];
+  float dot = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float d0 = d[2 * i], d1 = d[2 * i + 1];
+    if (do_rope) {
+      const float c = cs[2 * i], s = cs[2 * i + 1];
+      const float t0 = d0 * c + d1 * s;
+      const float t1 = d1 * c - d0 * s;
+      d0 = t0;
+      d1 = t1;
+    }
+    dn[2 * i] = d0 * w[2 * i];
+    dn[2 * i + 1] = d1 * w[2 * i + 1];
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    n[i] = x[i] * r;
+    dot += dn[i] * n[i];
+  }
+  dot += __shfl_xor(dot, 8, 64);
+  dot += __shfl_xor(dot, 4, 64);
+  dot += __shfl_xor(dot, 2, 64);
+  dot += __shfl_xor(dot, 1, 64);
+  dot *= (1.0f / 128.0f);
+  float o[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = r * (dn[i] - n[i] * dot);
+  *reinterpret_cast<u16x8*>(dxin) = pack8(o);
+}
+
+__global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(
+    const bf16_t* __restrict__ q_in, const bf16_t* __restrict__ k_in, const bf16_t* __restrict__ dq_out,
+    const bf16_t* __restrict__ dk_out, bf16_t* __restrict__ dq_in, bf16_t* __restrict__ dk_in,
+    const bf16_t* __restrict__ wq, const bf16_t* __restrict__ wk, const float* __restrict__ cs_tab, int H,
+    int64_t in_sb, int64_t in_sn, int64_t q_sb, int64_t q_sn, int64_t kv_sb, int64_t kv_sn, int64_t din_sb,
+    int64_t din_sn, int64_t pos_off, float eps) {
+  const int64_t n = blockIdx.x, b = blockIdx.y;
+  const int sub = threadIdx.x & 15;
+  const int hl = threadIdx.x >> 4;
+  float cs[8] = {1, 0, 1, 0, 1, 0, 1, 0};
+  const bool do_rope = cs_tab != nullptr;
+  if (do_rope) {
+    const float* p = cs_tab + ((pos_off + n) * 64 + sub * 4) * 2;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p);
+    const f32x4 c = *reinterpret_cast<const f32x4*>(p + 4);
+    cs[0] = a[0]; cs[1] = a[1]; cs[2] = a[2]; cs[3] = a[3];
+    cs[4] = c[0]; cs[5] = c[1]; cs[6] = c[2]; cs[7] = c[3];
+  }
+  float wqf[8], wkf[8];
+  unpack8(*reinterpret_cast<const u16x8*>(wq + sub * 8), wqf);
+  unpack8(*reinterpret_cast<const u16x8*>(wk + sub * 8), wkf);
+  for (int h0 = 0; h0 < H; h0 += 16) {
+    const int h = h0 + hl;
+    if (h >= H) continue;
+    const int64_t off = (int64_t)h * 128 + sub * 8;
+    if (q_in)
+      norm_rope_bwd_vec(q_in + b * in_sb + n * in_sn + off, dq_out + b * q_sb + n * q_sn + off,
+                        dq_in + b * din_sb + n * din_sn + off, wqf, cs, do_rope, eps);
+    if (k_in)
+      norm_rope_bwd_vec(k_in + b * in_sb + n * in_sn + off, dk_out + b * kv_sb + n * kv_sn + off,
+                        dk_in + b * din_sb + n * din_sn + off, wkf, cs, do_rope, eps);
+  }
+}
+
+extern "C" int lcv_qknorm_rope_bwd(const void* q_in, const void* k_in, const void* dq_out, const void* dk_out,
+                                   void* dq_in, void* dk_in, const void* wq, const void* wk, const void* cs,
+                                   int64_t B, int64_t N, int64_t H, int64_t in_sb, int64_t in_sn, int64_t q_sb,
+                                   int64_t q_sn, int64_t kv_sb, int64_t kv_sn, int64_t din_sb, int64_t din_sn,
+                                   int64_t pos_off, float eps, void* stream) {
+  LCV_CHECK_ARG((q_in || k_in) && wq && wk, "qknorm_rope_bwd: null pointer");
+  LCV_CHECK_ARG(!q_in || (dq_out && dq_in), "qknorm_rope_bwd: q gradients missing");
+  LCV_CHECK_ARG(!k_in || (dk_out && dk_in), "qknorm_rope_bwd: k gradients missing");
+  LCV_CHECK_ARG(in_sn % 8 == 0 && q_sn % 8 == 0 && kv_sn % 8 == 0 && din_sn % 8 == 0, "qknorm_rope_bwd: strides % 8");
+  if (B == 0 || N == 0) return LCV_OK;
+  hipLaunchKernelGGL(qknorm_rope_bwd_kernel, dim3((unsigned)N, (unsigned)B), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)q_in, (const bf16_t*)k_in, (const bf16_t*)dq_out, (const bf16_t*)dk_out,
+                     (bf16_t*)dq_in, (bf16_t*)dk_in, (const bf16_t*)wq, (const bf16_t*)wk, (const float*)cs,
+                     (int)H, in_sb, in_sn, q_sb, q_sn, kv_sb, kv_sn, din_sb, din_sn, pos_off, eps);
+  LCV_LAUNCH_CHECK("qknorm_rope_bwd");
+  return LCV_OK;
+}
+
+// ---------------------------------------------------------------------------
+// SwiGLU backward
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* __restrict__ gate,
+                                                         const bf16_t* __restrict__ up,
+                                                         const bf16_t* __restrict__ dout,
+                                                         bf16_t* __restrict__ dgate, bf16_t* __restrict__ dup,
+                                                         int64_t rows, int fpk, int64_t ld_in) {
+  const int64_t n_packets = rows * fpk;
+  for (int64_t pk = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; pk < n_packets;
+       pk += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = pk / fpk;
+    const int c = (int)(pk - row * fpk) * 8;
+    float g[8], u[8], d[8], og[8], ou[8];
+    unpack8(*reinterpret_cast<const u16x8*>(gate + row * ld_in + c), g);
+    unpack8(*reinterpret_cast<const u16x8*>(up + row * ld_in + c), u);
+    unpack8(*reinterpret_cast<const u16x8*>(dout + pk * 8), d);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float sig = 1.0f / (1.0f + __expf(-g[i]));
+      const float s = g[i] * sig;
+      ou[i] = d[i] * bfround(s);
+      og[i] = d[i] * u[i] * (sig * (1.0f + g[i] * (1.0f - sig)));
+    }
+    *reinterpret_cast<u16x8*>(dgate + pk * 8) = pack8(og);
+    *reinterpret_cast<u16x8*>(dup + pk * 8) = pack8(ou);
+  }
+}
+
+extern "C" int lcv_swiglu_bwd(const void* gate, const void* up, const void* dout, void* dgate, void* dup,
+                              int64_t rows, int64_t F, int64_t ld_in, void* stream) {
+  LCV_CHECK_ARG(gate && up && dout && dgate && dup, "swiglu_bwd: null pointer");
+  LCV_CHECK_ARG(F % 8 == 0 && ld_in % 8 == 0, "swiglu_bwd: F and ld_in must be multiples of 8");
+  const int64_t n_packets = rows * (F / 8);
+  if (n_packets == 0) return LCV_OK;
+  int64_t blocks = (n_packets + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(swiglu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)gate, (const bf16_t*)up, (const bf16_t*)dout, (bf16_t*)dgate, (bf16_t*)dup, rows,
+                     (int)(F / 8), ld_in);
+  LCV_LAUNCH_CHECK("swiglu_bwd");
+  return LCV_OK;
+}
+
+// ---------------------------------------------------------------------------
+// unpatchify backward: dout [B,Cout,T,H,W] fp32 -> dtok [B, N, (ph pw c)] fp32
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void unpatchify_bwd_kernel(const float* __restrict__ dout,
+                                                             float* __restrict__ dtok, int64_t B, int Cout, int T,
+                                                             int H, int W) {
+  const int Hh = H / 2, Wh = W / 2;
+  const int64_t total = (int64_t)B * T * Hh * Wh * 4 * Cout;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(i % (4 * Cout));
+    int64_t tkn = i / (4 * Cout);
+    const int c = k % Cout;
+    const int pp = k / Cout;  // ph*2 + pw
+    const int wq = (int)(tkn % Wh);
+    int64_t r = tkn / Wh;
+    const int hq = (int)(r % Hh);
+    r /= Hh;
+    const int t = (int)(r % T);
+    const int64_t b = r / T;
+    dtok[i] = dout[(((b * Cout + c) * T + t) * H + 2 * hq + (pp >> 1)) * (int64_t)W + 2 * wq + (pp & 1)];
+  }
+}
+
+extern "C" int lcv_unpatchify_bwd(const float* dout, float* dtok, int64_t B, int64_t Cout, int64_t T, int64_t H,
+                                  int64_t W, void* stream) {
+  LCV_CHECK_ARG(dout && dtok, "unpatchify_bwd: null pointer");
+  const int64_t total = B * Cout * T * H * W;
+  if (total == 0) return LCV_OK;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(unpatchify_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dout, dtok,
+                     B, (int)Cout, (int)T, (int)H, (int)W);
+  LCV_LAUNCH_CHECK("unpatchify_bwd");
+  return LCV_OK;
+}
+
+// ---------------------------------------------------------------------------
+// fp32 small-M linear backward w.r.t. its input:  da[m,k] = act'(a[m,k]) * sum_n dy[m,n] W[n,k]
+// Partial sums over 256-row slabs of W are accumulated with fp32 atomics into `da` (zero-filled here);
+// a second tiny launch applies the SiLU derivative.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void linear_f32_smallm_bwd_kernel(const float* __restrict__ dy,
+                                                                    const bf16_t* __restrict__ w,
+                                                                    float* __restrict__ da, int M, int64_t N, int K,
+                                                                    int nchunk) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* sdy = reinterpret_cast<float*>(smem);  // [M][nchunk]
+  const int64_t n0 = (int64_t)blockIdx.x * nchunk;
+  const int nn = (int)((N - n0) < nchunk ? (N - n0) : nchunk);
+  for (int i = threadIdx.x; i < M * nchunk; i += 256) {
+    const int m = i / nchunk, j = i - m * nchunk;
+    sdy[i] = (j < nn) ? dy[(int64_t)m * N + n0 + j] : 0.f;
+  }
+  __syncthreads();
+  for (int k0 = threadIdx.x * 2; k0 < K; k0 += 512) {
+    float acc0[16], acc1[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) { acc0[m] = 0.f; acc1[m] = 0.f; }
+    for (int j = 0; j < nn; ++j) {
+      const u16x2 wv = *reinterpret_cast<const u16x2*>(w + (n0 + j) * K + k0);
+      const float w0 = bf2f(wv[0]), w1 = bf2f(wv[1]);
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        if (m < M) {
+          const float d = sdy[m * nchunk + j];
+          acc0[m] += d * w0;
+          acc1[m] += d * w1;
+        }
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      if (m < M) {
+        atomicAdd(da + (int64_t)m * K + k0, acc0[m]);
+        atomicAdd(da + (int64_t)m * K + k0 + 1, acc1[m]);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void silu_grad_kernel(const float* __restrict__ a, float* __restrict__ da,
+                                                        int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const float x = a[i];
+    const float sig = 1.0f / (1.0f + __expf(-x));
+    da[i] *= sig * (1.0f + x * (1.0f - sig));
+  }
+}
+
+extern "C" int lcv_linear_f32_smallm_bwd(const float* dy, const void* w, const float* a, float* da, int64_t M,
+                                         int64_t N, int64_t K, int act_in, void* stream) {
+  LCV_CHECK_ARG(dy && w && a && da, "linear_f32_smallm_bwd: null pointer");
+  LCV_CHECK_ARG(K % 2 == 0, "linear_f32_smallm_bwd: K must be even");
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(da, 0, sizeof(float) * M * K, s) != hipSuccess) {
+    lcv_set_error("linear_f32_smallm_bwd: memset failed");
+    return LCV_EDEVICE;
+  }
+  const int nchunk = 256;
+  for (int64_t m0 = 0; m0 < M; m0 += 16) {
+    const int Mc = (int)((M - m0) < 16 ? (M - m0) : 16);
+    hipLaunchKernelGGL(linear_f32_smallm_bwd_kernel, dim3((unsigned)((N + nchunk - 1) / nchunk)), dim3(256),
+                       (size_t)Mc * nchunk * 4, s, dy + m0 * N, (const bf16_t*)w, da + m0 * K, Mc, N, (int)K, nchunk);
+    LCV_LAUNCH_CHECK("linear_f32_smallm_bwd");
+  }
+  if (act_in == 1) {
+    const int64_t n = M * K;
+    hipLaunchKernelGGL(silu_grad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, da, n);
+    LCV_LAUNCH_CHECK("silu_grad");
+  }
+  return LCV_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Skinny token contraction for the LoRA parameter gradients:
+//   out[r, k] += sum_m g[m, r] * x[m, k]      (g: [M, Rpad] bf16, x: [M, K] bf16, out: [R, K] fp32)
+// dA = (s dy B)^T x  and  dB^T = h^T dy  are both of this form.  HBM-bound on x (read once per 8 ranks);
+// each workgroup owns 2048 columns x 128 rows and publishes its partial with fp32 atomics (256-byte runs).
+// ---------------------------------------------------------------------------
+template <int RC>
+__global__ __launch_bounds__(256) void tn_skinny_kernel(const bf16_t* __restrict__ g, const bf16_t* __restrict__ x,
+                                                        float* __restrict__ out, int64_t M, int64_t K, int R,
+                                                        int Rpad, int64_t ldx, int r0, float scale) {
+  constexpr int ROWS = 128;
+  __shared__ float sg[ROWS][RC];
+  const int64_t m0 = (int64_t)blockIdx.y * ROWS;
+  const int64_t k = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+  const int nrows = (int)((M - m0) < ROWS ? (M - m0) : ROWS);
+  for (int i = threadIdx.x; i < ROWS * RC; i += 256) {
+    const int m = i / RC, rr = i - m * RC;
+    sg[m][rr] = (m < nrows && r0 + rr < R) ? bf2f(g[(m0 + m) * Rpad + r0 + rr]) : 0.f;
+  }
+  __syncthreads();
+  if (k >= K) return;
+  float acc[RC][8];
+#pragma unroll
+  for (int rr = 0; rr < RC; ++rr)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[rr][e] = 0.f;
+  for (int m = 0; m < nrows; ++m) {
+    float xf[8];
+    unpack8(*reinterpret_cast<const u16x8*>(x + (m0 + m) * ldx + k), xf);
+#pragma unroll
+    for (int rr = 0; rr < RC; ++rr) {
+      const float gv = sg[m][rr];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[rr][e] += gv * xf[e];
+    }
+  }
+#pragma unroll
+  for (int rr = 0; rr < RC; ++rr) {
+    if (r0 + rr < R) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) atomicAdd(out + (int64_t)(r0 + rr) * K + k + e, acc[rr][e] * scale);
+    }
+  }
+}
+
+extern "C" int lcv_tn_skinny(const void* g, const void* x, float* out, int64_t M, int64_t K, int64_t R,
+                             int64_t Rpad, int64_t ldx, float scale, void* stream) {
+  LCV_CHECK_ARG(g && x && out, "tn_skinny: null pointer");
+  LCV_CHECK_ARG(K % 8 == 0 && ldx % 8 == 0 && R >= 1 && R <= Rpad, "tn_skinny: bad shape");
+  if (M == 0) return LCV_OK;
+  const dim3 grid((unsigned)((K + 2047) / 2048), (unsigned)((M + 127) / 128));
+  for (int r0 = 0; r0 < R; r0 += 8) {
+    hipLaunchKernelGGL(tn_skinny_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)g,
+                       (const bf16_t*)x, out, M, K, (int)R, (int)Rpad, ldx, r0, scale);
+    LCV_LAUNCH_CHECK("tn_skinny");
+  }
+  return LCV_OK;
+}

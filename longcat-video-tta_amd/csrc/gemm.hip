@@ -362,46 +362,53 @@ extern "C" int lcv_linear_f32_smallm(const float* a, const void* w, const void* 
 }
 
 // ---------------------------------------------------------------------------
-// LoRA down-projection: h[M,Rpad] = bf16( s * bf16( x[M,K] A[R,K]^T ) ), zero padded.
-// HBM-bound on x (rank r flop/B): one wave per row, A held in LDS.
+// LoRA down-projection: h[M,Rpad] = bf16( s * bf16( x[M,K] A[R,K]^T ) ), zero padded to Rpad columns.
+// Also serves the backward g = s * dy B (x := dy, A := B^T).  HBM-bound on x (rank r flop/B):
+// one wave owns 4 rows so every 16-byte piece of A (L1/L2-resident, <= 800 KB) is reused 4 times.
 // ---------------------------------------------------------------------------
+template <int RMAX>
 __global__ __launch_bounds__(256) void lora_down_kernel(const bf16_t* __restrict__ x,
                                                         const bf16_t* __restrict__ A,
                                                         bf16_t* __restrict__ hout, int64_t M, int K, int R,
                                                         int Rpad, int64_t ldx, float s) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  bf16_t* sA = reinterpret_cast<bf16_t*>(smem);  // [R][K]
-  for (int i = threadIdx.x * 8; i < R * K; i += 256 * 8)
-    *reinterpret_cast<u16x8*>(sA + i) = *reinterpret_cast<const u16x8*>(A + i);
-  __syncthreads();
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < M; row += (int64_t)gridDim.x * 4) {
-    float acc[32];
+  const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+  if (row0 >= M) return;
+  int64_t rows[4];
 #pragma unroll
-    for (int j = 0; j < 32; ++j) acc[j] = 0.f;
-    for (int k = lane * 8; k < K; k += 512) {
-      float xf[8];
-      unpack8(*reinterpret_cast<const u16x8*>(x + row * ldx + k), xf);
+  for (int i = 0; i < 4; ++i) rows[i] = (row0 + i < M) ? row0 + i : M - 1;
+  float acc[4][RMAX];
 #pragma unroll
-      for (int j = 0; j < 32; ++j) {
-        if (j < R) {
-          float af[8];
-          unpack8(*reinterpret_cast<const u16x8*>(sA + j * K + k), af);
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int e = 0; e < 8; ++e) acc[j] += xf[e] * af[e];
-        }
+    for (int j = 0; j < RMAX; ++j) acc[i][j] = 0.f;
+  for (int k = lane * 8; k < K; k += 512) {
+    float xf[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) unpack8(*reinterpret_cast<const u16x8*>(x + rows[i] * ldx + k), xf[i]);
+#pragma unroll
+    for (int j = 0; j < RMAX; ++j) {
+      if (j < R) {
+        float af[8];
+        unpack8(*reinterpret_cast<const u16x8*>(A + (int64_t)j * K + k), af);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[i][j] += xf[i][e] * af[e];
       }
     }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
     float mine = 0.f;  // lane j keeps column j
 #pragma unroll
-    for (int j = 0; j < 32; ++j) {
+    for (int j = 0; j < RMAX; ++j) {
       if (j < R) {
-        const float t = wave_sum(acc[j]);
+        const float t = wave_sum(acc[i][j]);
         if (lane == j) mine = t;
       }
     }
-    if (lane < Rpad) hout[row * Rpad + lane] = (lane < R) ? f2bf(s * bfround(mine)) : (bf16_t)0;
+    if (row0 + i < M && lane < Rpad) hout[(row0 + i) * Rpad + lane] = (lane < R) ? f2bf(s * bfround(mine)) : (bf16_t)0;
   }
 }
 
@@ -409,21 +416,16 @@ extern "C" int lcv_lora_down(const void* x, const void* A, void* h, int64_t M, i
                              int64_t Rpad, int64_t ldx, float s, void* stream) {
   LCV_CHECK_ARG(x && A && h, "lora_down: null pointer");
   LCV_CHECK_ARG(R >= 1 && R <= 32 && Rpad >= R && Rpad <= 64, "lora_down: rank %ld unsupported (1..32, Rpad <= 64)", (long)R);
-  LCV_CHECK_ARG(K % 8 == 0 && ldx % 8 == 0 && R * K * 2 <= 160 * 1024 - 1024, "lora_down: bad K");
+  LCV_CHECK_ARG(K % 8 == 0 && ldx % 8 == 0, "lora_down: K and ldx must be multiples of 8");
   if (M == 0) return LCV_OK;
-  const size_t lds = (size_t)R * K * 2;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)lora_down_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024) != hipSuccess) {
-      lcv_set_error("lora_down: cannot raise dynamic LDS");
-      return LCV_EDEVICE;
-    }
-    attr_set = true;
-  }
-  int64_t blocks = (M + 3) / 4;
-  if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(lora_down_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream,
-                     (const bf16_t*)x, (const bf16_t*)A, (bf16_t*)h, M, (int)K, (int)R, (int)Rpad, ldx, s);
+  const unsigned blocks = (unsigned)((M + 15) / 16);
+  hipStream_t st = (hipStream_t)stream;
+  if (R <= 8)
+    hipLaunchKernelGGL(lora_down_kernel<8>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)A, (bf16_t*)h, M, (int)K, (int)R, (int)Rpad, ldx, s);
+  else if (R <= 16)
+    hipLaunchKernelGGL(lora_down_kernel<16>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)A, (bf16_t*)h, M, (int)K, (int)R, (int)Rpad, ldx, s);
+  else
+    hipLaunchKernelGGL(lora_down_kernel<32>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)A, (bf16_t*)h, M, (int)K, (int)R, (int)Rpad, ldx, s);
   LCV_LAUNCH_CHECK("lora_down");
   return LCV_OK;
 }

@@ -5,6 +5,7 @@ through a `torch.autograd.Function` whose backward is another HIP kernel when it
 loop).  Frozen base weights never get a gradient (LoRA-only backward): `dx = dy @ W` uses a
 resident transposed copy of W so that forward and backward share the one NT GEMM kernel.
 """
+import weakref
 from typing import List, Optional, Tuple
 
 import torch
@@ -23,19 +24,20 @@ def _needs_grad(*ts) -> bool:
 
 
 # --------------------------------------------------------------------------- transposed weights
-_WT_CACHE = {}
+_WT_CACHE = {}  # id(weight) -> (weakref to the weight, version, W^T)
 
 
 def transposed_weight(w: torch.Tensor) -> torch.Tensor:
-    """Resident W^T ([in, out], contiguous) for dx = dy @ W; rebuilt if the weight is modified."""
-    key = w.data_ptr()
+    """Resident W^T ([in, out], contiguous) for dx = dy @ W.  Entries are tied to the weight OBJECT (a freed model's
+    storage address can be reused by the next one) and rebuilt when the weight is modified in place."""
+    key = id(w)
     ent = _WT_CACHE.get(key)
-    if ent is None or ent[0] != w._version or ent[1].shape != (w.shape[1], w.shape[0]):
-        with torch.no_grad():
-            wt = w.detach().t().contiguous()
-        _WT_CACHE[key] = (w._version, wt)
-        return wt
-    return ent[1]
+    if ent is not None and ent[0]() is w and ent[1] == w._version and ent[2].data_ptr() != 0:
+        return ent[2]
+    with torch.no_grad():
+        wt = w.detach().t().contiguous()
+    _WT_CACHE[key] = (weakref.ref(w, lambda _r, k=key: _WT_CACHE.pop(k, None)), w._version, wt)
+    return wt
 
 
 def clear_weight_caches():

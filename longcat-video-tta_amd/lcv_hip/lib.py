@@ -5,12 +5,12 @@ is no CPU or eager-PyTorch fallback anywhere above it.
 """
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_void_p
 from pathlib import Path
 
 _LIB_PATH = Path(__file__).resolve().parent / "liblcv_hip.so"
 
-P, I64, F32, I = c_void_p, c_int64, c_float, c_int
+P, I64, F32, I, F64 = c_void_p, c_int64, c_float, c_int, c_double
 
 # name -> argtypes (every function returns int)
 _SIGNATURES = {
@@ -22,28 +22,25 @@ _SIGNATURES = {
     "lcv_gate_residual_fwd": [P, P, P, P, I64, I64, I64, I64, I64, I64, P],
     "lcv_gate_residual_bwd": [P, P, P, P, P, I64, I64, I64, I64, I64, I64, P],
     "lcv_qknorm_rope_fwd": [P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, F32, P],
-    "lcv_qknorm_rope_bwd": [P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64,
-                            I64, I64, I64, F32, P],
+    "lcv_qknorm_rope_bwd": [P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, F32, P],
     "lcv_attn_fwd": [P, P, P, P, P, I64, I64, I64, I64] + [I64] * 12 + [F32, P],
-    "lcv_attn_bwd": [P, P, P, P, P, P, P, P, P, P, P, I64, I64, I64, I64] + [I64] * 21 + [F32, P],
+    "lcv_attn_bwd": [P, P, P, P, P, P, P, P, P, P, I, I64, I64, I64, I64] + [I64] * 21 + [F32, P],
     "lcv_gemm_nt": [P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, I, I, P, P, I64, I64, I64, P],
     "lcv_linear_f32_smallm": [P, P, P, P, I64, I64, I64, I, P],
     "lcv_lora_down": [P, P, P, I64, I64, I64, I64, I64, F32, P],
-    "lcv_lora_bwd_dB_g": [P, P, P, P, P, I64, I64, I64, I64, I64, F32, P],
-    "lcv_lora_bwd_dA": [P, P, P, I64, I64, I64, I64, I64, P],
+    "lcv_tn_skinny": [P, P, P, I64, I64, I64, I64, I64, F32, P],
+    "lcv_linear_f32_smallm_bwd": [P, P, P, P, I64, I64, I64, I, P],
     "lcv_swiglu_fwd": [P, P, P, I64, I64, I64, P],
     "lcv_swiglu_bwd": [P, P, P, P, P, I64, I64, I64, P],
     "lcv_patchify": [P, P, I64, I64, I64, I64, I64, I64, P],
     "lcv_unpatchify": [P, P, I64, I64, I64, I64, I64, I, P],
+    "lcv_unpatchify_bwd": [P, P, I64, I64, I64, I64, I64, P],
     "lcv_cfg_euler_step": [P, P, P, P, I64, I64, F32, F32, I, I, P],
     "lcv_euler_step": [P, P, I64, F32, I, P],
     "lcv_fm_noise": [P, P, P, P, I64, I64, P],
     "lcv_fm_mse": [P, P, P, P, P, I64, I64, I64, I64, I64, P],
-    "lcv_grad_norm_sq": [P, I64, I, P, P],
-    "lcv_adamw_clip_step": [P, I64, I, P, F32, F32, F32, F32, F32, F32, I64, P],
-    "lcv_causal_conv3d": [P, P, P, P, P, I64, I64, I64, I64, I64, I64, I, I, I, P],
-    "lcv_vae_rmsnorm_silu": [P, P, P, I64, I64, I, P],
-    "lcv_upsample2x": [P, P, I64, I64, I64, I64, P],
+    "lcv_grad_norm_clip": [P, I64, I64, I, F32, P, P, P],
+    "lcv_adamw_step": [P, I64, I64, I, P, F64, F64, F64, F64, F64, I64, P],
 }
 
 LCV_EPI_NONE, LCV_EPI_SWIGLU, LCV_EPI_GATE_RESIDUAL, LCV_EPI_GELU_TANH, LCV_EPI_SILU = 0, 1, 2, 3, 4

@@ -147,8 +147,11 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = Non
     N = w.shape[0]
     if w.shape[1] != K:
         raise _lib.LcvError(f"gemm_nt: K mismatch ({K} vs {w.shape[1]})")
-    if K % 64:
-        raise _lib.LcvError("gemm_nt: K must be a multiple of 64 (pad on the host)")
+    if K % 64:  # rare (toy shapes): zero-pad the contraction dim to the kernel's 64-deep K step
+        pad = 64 - K % 64
+        a = torch.nn.functional.pad(a, (0, pad))
+        w = torch.nn.functional.pad(w, (0, pad))
+        K += pad
     K2 = 0
     if a2 is not None:
         _req(a2, BF16, "gemm_nt.a2"); _req(w2, BF16, "gemm_nt.w2")
@@ -251,3 +254,179 @@ def fm_mse(pred: torch.Tensor, eps: torch.Tensor, x0: torch.Tensor, Tc: int, nee
     call("lcv_fm_mse", _ptr(pred.contiguous()), _ptr(eps.contiguous()), _ptr(x0.contiguous()), _ptr(loss),
          _ptr(dpred), B, C, T, Tc, H * W, _stream())
     return loss[0], dpred
+
+
+# ===================================================================== backward kernels
+def adaln_modulate_bwd(x, mod, dy, shift_idx, scale_idx, T, eps=1e-6, need_dmod=False):
+    _req(dy, BF16, "adaln_modulate_bwd.dy")
+    B, N, C = x.shape
+    dx = torch.empty_like(x)
+    dmod = torch.zeros_like(mod) if need_dmod else None
+    call("lcv_adaln_modulate_bwd", _ptr(x), _ptr(mod), _ptr(dy), _ptr(dx), _ptr(dmod), B, T, N // T, C,
+         mod.shape[-1], shift_idx * C, scale_idx * C, eps, _stream())
+    return dx, dmod
+
+
+def layernorm_affine_bwd(x, w, dy, eps=1e-6, need_dw=False):
+    _req(dy, BF16, "layernorm_affine_bwd.dy")
+    C = x.shape[-1]
+    x = x.contiguous()
+    wf = w.detach().to(F32).contiguous()
+    dx = torch.empty_like(x)
+    dw = torch.zeros(C, dtype=F32, device=x.device) if need_dw else None
+    db = torch.zeros(C, dtype=F32, device=x.device) if need_dw else None
+    call("lcv_layernorm_affine_bwd", _ptr(x), _ptr(wf), _ptr(dy), _ptr(dx), _ptr(dw), _ptr(db), x.numel() // C, C,
+         eps, _stream())
+    return dx, dw, db
+
+
+def gate_residual_bwd(y, mod, dout, gate_idx, T, need_dmod=False):
+    _req(dout, BF16, "gate_residual_bwd.dout")
+    B, N, C = y.shape
+    dy = torch.empty_like(y)
+    dmod = torch.zeros_like(mod) if need_dmod else None
+    call("lcv_gate_residual_bwd", _ptr(y), _ptr(mod), _ptr(dout), _ptr(dy), _ptr(dmod), B, T, N // T, C,
+         mod.shape[-1], gate_idx * C, _stream())
+    return dy, dmod
+
+
+def qknorm_rope_bwd(q_in, k_in, dq_out, dk_out, dq_in, dk_in, wq, wk, cs, pos_off=0, eps=1e-6):
+    ref = q_in if q_in is not None else k_in
+    B, N, H, D = ref.shape
+    go = dq_out if dq_out is not None else dk_out
+    gk = dk_out if dk_out is not None else dq_out
+    gi = dq_in if dq_in is not None else dk_in
+    for t in (q_in, k_in, dq_out, dk_out, dq_in, dk_in):
+        if t is not None and (t.stride(3) != 1 or t.stride(2) != D):
+            raise _lib.LcvError("qknorm_rope_bwd: (H, D) must be contiguous")
+    call("lcv_qknorm_rope_bwd", _ptr(q_in), _ptr(k_in), _ptr(dq_out), _ptr(dk_out), _ptr(dq_in), _ptr(dk_in),
+         _ptr(wq), _ptr(wk), _ptr(cs), B, N, H, ref.stride(0), ref.stride(1), go.stride(0), go.stride(1),
+         gk.stride(0), gk.stride(1), gi.stride(0), gi.stride(1), pos_off, eps, _stream())
+
+
+def attention_bwd(q, k, v, o, do, lse, dq, dk, dv, scale, accumulate_kv=False):
+    """All [B,N,H,128] views; do must share o's strides; dq/dk/dv written (dk/dv accumulated when asked)."""
+    B, Nq, H, D = q.shape
+    Nk = k.shape[1]
+    if do.stride() != o.stride():
+        do = do.contiguous()
+        if do.stride() != o.stride():
+            raise _lib.LcvError("attention_bwd: dO must share O's strides")
+    delta = torch.empty((B, H, Nq), dtype=F32, device=q.device)
+    call("lcv_attn_bwd", _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(do), _ptr(lse), _ptr(dq), _ptr(dk), _ptr(dv),
+         _ptr(delta), 1 if accumulate_kv else 0, B, H, Nq, Nk,
+         q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2),
+         v.stride(0), v.stride(1), v.stride(2), o.stride(0), o.stride(1), o.stride(2),
+         dq.stride(0), dq.stride(1), dq.stride(2), dk.stride(0), dk.stride(1), dk.stride(2),
+         dv.stride(0), dv.stride(1), dv.stride(2), float(scale), _stream())
+
+
+def swiglu_bwd(gate, up, dout):
+    rows, F = gate.shape
+    dg = torch.empty((rows, F), dtype=BF16, device=gate.device)
+    du = torch.empty((rows, F), dtype=BF16, device=gate.device)
+    call("lcv_swiglu_bwd", _ptr(gate), _ptr(up), _ptr(dout), _ptr(dg), _ptr(du), rows, F, gate.stride(0), _stream())
+    return dg, du
+
+
+def unpatchify_bwd(dout, Cout, T, H, W):
+    _req(dout, F32, "unpatchify_bwd.dout")
+    B = dout.shape[0]
+    dtok = torch.empty((B, T * (H // 2) * (W // 2), 4 * Cout), dtype=F32, device=dout.device)
+    call("lcv_unpatchify_bwd", _ptr(dout), _ptr(dtok), B, Cout, T, H, W, _stream())
+    return dtok
+
+
+def linear_f32_smallm_bwd(dy, w, a, act_in=0):
+    _req(dy, F32, "linear_f32_smallm_bwd.dy")
+    M, K = a.shape
+    N = w.shape[0]
+    da = torch.empty((M, K), dtype=F32, device=a.device)
+    call("lcv_linear_f32_smallm_bwd", _ptr(dy.contiguous()), _ptr(w.contiguous()), _ptr(a.contiguous()), _ptr(da),
+         M, N, K, act_in, _stream())
+    return da
+
+
+def tn_skinny(g, x, R, scale=1.0):
+    """out[R, K] fp32 = scale * g[:, :R]^T @ x  (g [M, Rpad] bf16, x [M, K] bf16)."""
+    _req(g, BF16, "tn_skinny.g"); _req(x, BF16, "tn_skinny.x")
+    M, K = x.shape
+    out = torch.zeros((R, K), dtype=F32, device=x.device)
+    call("lcv_tn_skinny", _ptr(g), _ptr(x), _ptr(out), M, K, R, g.shape[1], x.stride(0), float(scale), _stream())
+    return out
+
+
+# ===================================================================== fused clip + AdamW
+class FusedAdamWClip:
+    """clip_grad_norm_ + AdamW.step over a fixed parameter list in two launches (norm, update).
+
+    Mirrors `AdamW(lora_params, lr, betas=(0.9, 0.999), weight_decay, eps=1e-8)` +
+    `clip_grad_norm_(lora_params, max_norm)` of lora_experiment/scripts/run_lora_tta.py:462-468, 513-514,
+    including the bf16 rounding points of the foreach implementation.  `param_groups` is kept so the reference's
+    warm-up loop (`for pg in optimizer.param_groups: pg["lr"] = ...`) works unchanged."""
+    CHUNK = 2048
+
+    def __init__(self, params, lr=2e-4, betas=(0.9, 0.999), weight_decay=0.01, eps=1e-8):
+        self.params = [p for p in params]
+        if not self.params:
+            raise ValueError("optimizer got an empty parameter list")
+        dt = self.params[0].dtype
+        if dt not in (BF16, F32) or any(p.dtype != dt for p in self.params):
+            raise _lib.LcvError("FusedAdamWClip: parameters must be all bf16 or all fp32")
+        self.f32 = dt == F32
+        self.param_groups = [dict(params=self.params, lr=lr, betas=betas, weight_decay=weight_decay, eps=eps)]
+        self.exp_avg = [torch.zeros_like(p) for p in self.params]
+        self.exp_avg_sq = [torch.zeros_like(p) for p in self.params]
+        self.step_count = 0
+        dev = self.params[0].device
+        self._ws = torch.zeros(len(self.params), dtype=F32, device=dev)
+        self._norm_coef = torch.zeros(2, dtype=F32, device=dev)
+        self._desc = None
+        self._desc_key = None
+        self._have_coef = False
+
+    def zero_grad(self, set_to_none: bool = True):
+        for p in self.params:
+            p.grad = None if set_to_none else (p.grad.zero_() if p.grad is not None else None)
+        self._have_coef = False
+
+    def _descriptors(self):
+        """Device descriptor table over the parameters that received a gradient (torch's AdamW and
+        clip_grad_norm_ skip `grad is None` the same way)."""
+        sel, grads = [], []
+        for i, p in enumerate(self.params):
+            if p.grad is None:
+                continue
+            sel.append(i)
+            grads.append(p.grad if p.grad.is_contiguous() else p.grad.contiguous())
+        if not sel:
+            raise _lib.LcvError("FusedAdamWClip: no parameter has a gradient")
+        key = tuple(g.data_ptr() for g in grads) + tuple(sel)
+        if self._desc is None or key != self._desc_key:
+            rows, chunk = [], 0
+            for i, g in zip(sel, grads):
+                p, m, v = self.params[i], self.exp_avg[i], self.exp_avg_sq[i]
+                rows.append([p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), chunk])
+                chunk += (p.numel() + self.CHUNK - 1) // self.CHUNK
+            self._desc = torch.tensor(rows, dtype=torch.int64).to(self.params[0].device)
+            self._total_chunks = chunk
+            self._n_active = len(sel)
+            self._desc_key = key
+        self._grads = grads  # keep alive until the launch
+        return self._desc
+
+    def clip_grad_norm_(self, max_norm: float) -> torch.Tensor:
+        d = self._descriptors()
+        call("lcv_grad_norm_clip", _ptr(d), self._n_active, self._total_chunks, 1 if self.f32 else 0,
+             float(max_norm), _ptr(self._ws), _ptr(self._norm_coef), _stream())
+        self._have_coef = True
+        return self._norm_coef[0]
+
+    def step(self):
+        d = self._descriptors()
+        g = self.param_groups[0]
+        self.step_count += 1
+        call("lcv_adamw_step", _ptr(d), self._n_active, self._total_chunks, 1 if self.f32 else 0,
+             _ptr(self._norm_coef) if self._have_coef else None, float(g["lr"]), float(g["betas"][0]),
+             float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), self.step_count, _stream())
+        self._have_coef = False

@@ -1,0 +1,285 @@
+"""GPU parity of the backward kernels and the TTA inner loop.
+
+References: torch autograd over the CPU oracle functions in fp32 (no bf16 rounding: roundings are straight-through
+in both), and the golden vectors minted from the reference's own LoRALinear / AdamW / inner loop.
+Tolerances: gradients are bf16 tensors -> relative L2 <= 1e-2 against the fp32 autograd reference (inputs are bf16,
+P/dS are rounded to bf16 before their MFMAs exactly like the forward); optimizer results bit-exact up to the stated
+fraction of 1-ulp flips caused by the norm's summation order.
+"""
+import json
+from pathlib import Path
+
+import pytest
+import torch
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+BF16 = torch.bfloat16
+DEV = "cuda"
+G = Path(__file__).resolve().parent / "golden"
+
+
+def _randn(*shape, seed=0, scale=1.0, dtype=BF16):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype)
+
+
+@pytest.mark.parametrize("B,H,Nq,Nk", [(1, 2, 200, 200), (2, 1, 70, 333), (1, 1, 256, 128), (1, 2, 33, 5)])
+def test_attention_backward(B, H, Nq, Nk):
+    from lcv_hip import ops
+    D = 128
+    q = _randn(B, Nq, H, D, seed=1); k = _randn(B, Nk, H, D, seed=2); v = _randn(B, Nk, H, D, seed=3)
+    do = _randn(B, Nq, H, D, seed=4)
+    scale = D ** -0.5
+    qd, kd, vd, dod = q.to(DEV), k.to(DEV), v.to(DEV), do.to(DEV)
+    o, lse = ops.attention(qd, kd, vd, scale, need_lse=True)
+    dq = torch.empty_like(qd); dk = torch.empty_like(kd); dv = torch.empty_like(vd)
+    ops.attention_bwd(qd, kd, vd, o, dod, lse, dq, dk, dv, scale)
+    qf, kf, vf = (t.float().permute(0, 2, 1, 3).requires_grad_(True) for t in (q, k, v))
+    s = (qf @ kf.transpose(-1, -2)) * scale
+    ref = torch.softmax(s, -1) @ vf
+    ref.backward(do.float().permute(0, 2, 1, 3))
+    assert rel_l2(dq.permute(0, 2, 1, 3), qf.grad) < 1e-2
+    assert rel_l2(dk.permute(0, 2, 1, 3), kf.grad) < 1e-2
+    assert rel_l2(dv.permute(0, 2, 1, 3), vf.grad) < 1e-2
+    # accumulate_kv adds into existing dk/dv
+    dk2 = dk.clone(); dv2 = dv.clone()
+    ops.attention_bwd(qd, kd, vd, o, dod, lse, dq, dk2, dv2, scale, accumulate_kv=True)
+    assert rel_l2(dk2, 2 * dk.float()) < 1e-2 and rel_l2(dv2, 2 * dv.float()) < 1e-2
+
+
+def test_norm_gate_swiglu_backward():
+    from lcv_hip import ops
+    from oracle import dit_oracle as orc
+    import torch.nn.functional as F
+    B, T, S, C = 2, 3, 9, 512
+    x = _randn(B, T * S, C, seed=5); dy = _randn(B, T * S, C, seed=6)
+    mod = _randn(B, T, 6 * C, seed=7, scale=0.5, dtype=torch.float32)
+    dx, dmod = ops.adaln_modulate_bwd(x.to(DEV), mod.to(DEV), dy.to(DEV), 0, 1, T, need_dmod=True)
+    xf = x.float().requires_grad_(True); mf = mod.clone().requires_grad_(True)
+    y = orc.modulate_fp32(xf.view(B, T, S, C), mf[..., :C].unsqueeze(2), mf[..., C:2 * C].unsqueeze(2))
+    y.backward(dy.float().view(B, T, S, C))
+    assert rel_l2(dx, xf.grad) < 5e-3 and rel_l2(dmod, mf.grad) < 1e-4
+    # affine LayerNorm with parameter grads
+    w = _randn(C, seed=8); b = _randn(C, seed=9)
+    dx, dw, db = ops.layernorm_affine_bwd(x.to(DEV), w.to(DEV), dy.to(DEV), need_dw=True)
+    xf = x.float().requires_grad_(True); wf = w.float().requires_grad_(True); bf = b.float().requires_grad_(True)
+    orc.layernorm_fp32(xf, wf, bf).backward(dy.float())
+    assert rel_l2(dx, xf.grad) < 5e-3 and rel_l2(dw, wf.grad) < 1e-4 and rel_l2(db, bf.grad) < 1e-4
+    # gated residual
+    yv = _randn(B, T * S, C, seed=10)
+    dyy, dmod = ops.gate_residual_bwd(yv.to(DEV), mod.to(DEV), dy.to(DEV), 2, T, need_dmod=True)
+    g = mod[..., 2 * C:3 * C].unsqueeze(2)
+    assert rel_l2(dyy, (g * dy.float().view(B, T, S, C)).view(B, T * S, C)) < 5e-3
+    ref_dg = (dy.float() * yv.float()).view(B, T, S, C).sum(2)
+    assert rel_l2(dmod[..., 2 * C:3 * C], ref_dg) < 1e-4 and dmod[..., :2 * C].abs().max().item() == 0
+    # swiglu
+    gte = _randn(40, 256, seed=11); up = _randn(40, 256, seed=12); dout = _randn(40, 256, seed=13)
+    dg, du = ops.swiglu_bwd(gte.to(DEV), up.to(DEV), dout.to(DEV))
+    gf = gte.float().requires_grad_(True); uf = up.float().requires_grad_(True)
+    (F.silu(gf) * uf).backward(dout.float())
+    assert rel_l2(dg, gf.grad) < 5e-3 and rel_l2(du, uf.grad) < 5e-3
+
+
+def test_qknorm_rope_backward():
+    from lcv_hip import ops
+    from oracle import dit_oracle as orc
+    grid, H, D, B = (2, 3, 4), 2, 128, 1
+    N = 24
+    qkv = _randn(B, N, 3, H, D, seed=14)
+    wq = (1 + 0.1 * _randn(D, seed=15).float()).to(BF16); wk = (1 + 0.1 * _randn(D, seed=16).float()).to(BF16)
+    dq = _randn(B, N, H, D, seed=17); dk = _randn(B, N, H, D, seed=18)
+    cs = orc.rope_cos_sin_table(grid, D)
+    d = qkv.to(DEV)
+    dqi = torch.empty(B, N, H, D, dtype=BF16, device=DEV); dki = torch.empty_like(dqi)
+    ops.qknorm_rope_bwd(d[:, :, 0], d[:, :, 1], dq.to(DEV), dk.to(DEV), dqi, dki, wq.to(DEV), wk.to(DEV), cs.to(DEV))
+    ang = orc.rope_angles_3d(grid, D)
+    for idx, w, dout, got in ((0, wq, dq, dqi), (1, wk, dk, dki)):
+        src = qkv[:, :, idx].float().permute(0, 2, 1, 3).requires_grad_(True)
+        out = orc.apply_rope(orc.rmsnorm_fp32(src, w), ang)
+        out.backward(dout.float().permute(0, 2, 1, 3))
+        assert rel_l2(got.permute(0, 2, 1, 3), src.grad) < 5e-3, idx
+
+
+def test_linear_f32_backward_and_tn_skinny_and_unpatchify():
+    from lcv_hip import ops
+    import torch.nn.functional as F
+    a = _randn(26, 512, seed=19, dtype=torch.float32); w = _randn(1536, 512, seed=20, scale=0.05)
+    dy = _randn(26, 1536, seed=21, dtype=torch.float32)
+    da = ops.linear_f32_smallm_bwd(dy.to(DEV), w.to(DEV), a.to(DEV), act_in=1)
+    af = a.clone().requires_grad_(True)
+    (F.silu(af) @ w.float().t()).backward(dy)
+    assert rel_l2(da, af.grad) < 1e-4
+    g = _randn(300, 64, seed=22); x = _randn(300, 4096, seed=23)
+    out = ops.tn_skinny(g.to(DEV), x.to(DEV), 8, scale=2.0)
+    assert rel_l2(out, 2.0 * g[:, :8].float().t() @ x.float()) < 1e-4
+    out = ops.tn_skinny(g.to(DEV), x.to(DEV), 20, scale=1.0)
+    assert rel_l2(out, g[:, :20].float().t() @ x.float()) < 1e-4
+    dout = _randn(2, 16, 3, 8, 12, seed=24, dtype=torch.float32)
+    dtok = ops.unpatchify_bwd(dout.to(DEV), 16, 3, 8, 12)
+    from oracle import dit_oracle as orc
+    t = torch.zeros(2, 3 * 4 * 6, 64, requires_grad=True)
+    orc.unpatchify(t, 3, 4, 6, (1, 2, 2), 16).backward(dout)
+    assert torch.equal(dtok.cpu(), t.grad)
+
+
+def test_lora_linear_matches_reference_fixture():
+    """Fused LoRALinear forward/backward against vectors produced by the reference's own LoRALinear."""
+    import torch.nn as nn
+    from tta.lora import LoRALinear
+    from longcat_video.modules.layers import HipLinear
+    t = torch.load(G / "tta_tensors.pt")["lora_linear_bf16"]
+    base = HipLinear(64, 96, device=DEV, dtype=BF16)
+    with torch.no_grad():
+        base.weight.copy_(t["W"]); base.bias.copy_(t["b"])
+    base.weight.requires_grad_(False); base.bias.requires_grad_(False)
+    lora = LoRALinear(base, rank=4, alpha=16.0).to(device=DEV, dtype=BF16)
+    with torch.no_grad():
+        lora.lora_down.weight.copy_(t["A"]); lora.lora_up.weight.copy_(t["B"])
+    x = t["x"].to(DEV).requires_grad_(True)
+    y = lora(x)
+    y.backward(t["gy"].to(DEV))
+    assert abs(lora.scaling - float(t["scaling"])) < 1e-12
+    # the reference rounds after every bf16 op; the fused path accumulates in fp32 -> compare within bf16 noise
+    assert rel_l2(y, t["y"].float()) < 6e-3
+    assert rel_l2(x.grad, t["dx"].float()) < 1e-2
+    assert rel_l2(lora.lora_down.weight.grad, t["dA"].float()) < 1e-2
+    assert rel_l2(lora.lora_up.weight.grad, t["dB"].float()) < 1e-2
+
+
+def test_fused_adamw_clip_matches_reference_trace():
+    from lcv_hip.ops import FusedAdamWClip
+    tr = torch.load(G / "tta_tensors.pt")["adamw_trace"]
+    ps = [torch.nn.Parameter(p.to(DEV)) for p in tr["init"]]
+    opt = FusedAdamWClip(ps, lr=2e-3, betas=(0.9, 0.999), weight_decay=0.01, eps=1e-8)
+    mism = tot = 0
+    for step in range(len(tr["grads"])):
+        if step < 3:
+            for pg in opt.param_groups:
+                pg["lr"] = 2e-3 * (step + 1) / 3
+        for p, g in zip(ps, tr["grads"][step]):
+            p.grad = g.to(DEV).clone()
+        n = opt.clip_grad_norm_(1.0)
+        opt.step()
+        assert abs(n.item() - float(tr["norms"][step])) <= 2 ** -7 * float(tr["norms"][step])
+        for p, exp in zip(ps, tr["after"][step]):
+            d = (p.detach().cpu().view(torch.int16).int() - exp.view(torch.int16).int()).abs()
+            assert d.max().item() <= 1, (step, d.max().item())   # at most one bf16 ulp apart
+            mism += (d != 0).sum().item(); tot += d.numel()
+    assert mism / tot < 0.02, f"{mism}/{tot} elements differ from torch's AdamW"
+
+
+def _small_dit(depth=2):
+    from oracle import dit_oracle as orc
+    from longcat_video.modules.longcat_video_dit import LongCatVideoTransformer3DModel
+    cfg = orc.small_config(hidden_size=256, depth=depth, num_heads=2, caption_channels=64)
+    P = orc.make_params(cfg, seed=21, std=0.05)
+    m = LongCatVideoTransformer3DModel(device=DEV, dtype=BF16, hidden_size=256, depth=depth, num_heads=2,
+                                       caption_channels=64, adaln_tembed_dim=64)
+    m.load_state_dict(P, strict=False)
+    return m, cfg, P
+
+
+@pytest.mark.parametrize("ncond,ckpt", [(1, False), (0, False), (1, True), (0, True)])
+def test_dit_lora_gradients_match_oracle_autograd(ncond, ckpt):
+    """loss.backward() through the HIP DiT with fused LoRA adapters vs torch autograd over the fp32 oracle with the
+    same adapters folded in as W + s*B*A (mathematically identical)."""
+    import functools
+    from torch.utils.checkpoint import checkpoint
+    from oracle import dit_oracle as orc
+    from tta.lora import inject_lora_into_dit, get_lora_parameters
+    from tta.flow_matching import fm_mse_loss
+    m, cfg, P = _small_dit()
+    for p in m.parameters():
+        p.requires_grad = False
+    mods = inject_lora_into_dit(m, rank=4, alpha=8.0, target_modules=["qkv", "proj"], target_ffn=True)
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for lm in mods:
+            lm.lora_down.weight.copy_((torch.randn(lm.lora_down.weight.shape, generator=g) * 0.05).to(BF16))
+            lm.lora_up.weight.copy_((torch.randn(lm.lora_up.weight.shape, generator=g) * 0.05).to(BF16))
+    if ckpt:  # the reference's gradient-checkpointing switch (run_lora_tta.py:806-811)
+        m.gradient_checkpointing = True
+        m._gradient_checkpointing_func = functools.partial(checkpoint, use_reentrant=False)
+    m.train()
+    B, T, H, W, L = 1, 3, 8, 8, 16
+    hs = _randn(B, 16, T, H, W, seed=30); y = _randn(B, 1, L, 64, seed=31)
+    mask = torch.zeros(B, L, dtype=torch.int64); mask[:, :11] = 1
+    ts = torch.zeros(B, T); ts[:, ncond:] = 431.0
+    eps = _randn(B, 16, T - ncond, H, W, seed=32); x0 = _randn(B, 16, T - ncond, H, W, seed=33)
+    pred = m(hs.to(DEV), ts.to(BF16).to(DEV), y.to(DEV), mask.to(DEV), num_cond_latents=ncond)
+    loss = fm_mse_loss(pred, eps.to(DEV), x0.to(DEV), ncond)
+    loss.backward()
+    # ---- oracle with folded adapters
+    names = []
+    for i in range(cfg["depth"]):
+        b = f"blocks.{i}."
+        names += [b + "attn.qkv", b + "attn.proj", b + "cross_attn.q_linear", b + "cross_attn.kv_linear",
+                  b + "cross_attn.proj", b + "ffn.w1", b + "ffn.w2", b + "ffn.w3"]
+    P2 = {k: v.float() for k, v in P.items()}
+    leaves = []
+    for n, lm in zip(names, mods):
+        A_ = lm.lora_down.weight.detach().float().cpu().requires_grad_(True)
+        B_ = lm.lora_up.weight.detach().float().cpu().requires_grad_(True)
+        P2[n + ".weight"] = P2[n + ".weight"] + lm.scaling * (B_ @ A_)
+        leaves += [A_, B_]
+    ref = orc.dit_forward(P2, cfg, hs, ts.to(BF16), y, mask, ncond, bf16=False)
+    ref_loss = torch.nn.functional.mse_loss(ref[:, :, ncond:], (eps - x0).float())
+    ref_loss.backward()
+    assert abs(loss.item() - ref_loss.item()) < 2e-2 * abs(ref_loss.item())
+    got = get_lora_parameters(mods)
+    errs = [rel_l2(p.grad, l.grad) for p, l in zip(got, leaves)]
+    print("max / median LoRA grad rel-L2:", max(errs), sorted(errs)[len(errs) // 2])
+    print([f"{n.split('blocks.')[1]}:{e1:.3f}/{e2:.3f}" for n, e1, e2 in zip(names, errs[0::2], errs[1::2])])
+    assert max(errs) < 6e-2 and sorted(errs)[len(errs) // 2] < 3e-2
+
+
+def test_inner_loop_matches_reference_run():
+    """finetune_lora_on_conditioning (fused LoRA + fused clip/AdamW) against the losses and final adapter weights the
+    reference's own loop produced on the toy DiT of tests/golden/make_golden.py (same injected sigma / eps)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", G / "make_golden.py")
+    mg = importlib.util.module_from_spec(spec); spec.loader.exec_module(mg)
+    from tta.lora import inject_lora_into_dit, get_lora_parameters
+    from tta.inner_loop import finetune_lora_on_conditioning
+    t = torch.load(G / "tta_tensors.pt")["inner_loop"]
+    inj = json.loads((G / "lora_injection.json").read_text())
+    dit = mg.ToyDiT(dtype=BF16)
+    # the fixture was saved after injection: wrapped linears appear as `<name>.original.<param>`
+    dit.load_state_dict({k.replace(".original.", "."): v for k, v in t["base_state"].items()}, strict=True)
+    dit.to(DEV)
+    for p in dit.parameters():
+        p.requires_grad = False
+    hp = t["hp"]
+    mods = inject_lora_into_dit(dit, rank=hp["rank"], alpha=hp["alpha"], target_modules=["qkv", "proj"],
+                                target_ffn=True, target_blocks="last_2")
+    order = [n for n, mm in dit.named_modules() if type(mm).__name__ == "LoRALinear"]
+    assert order == inj["named_modules_order"] and len(mods) == inj["n_modules"]
+    params = get_lora_parameters(mods)
+    assert [list(p.shape) for p in params] == inj["param_shapes"]
+    with torch.no_grad():
+        for p, v in zip(params, t["init_params"]):
+            p.copy_(v)
+    cnt = {"i": 0}
+    real_rand, real_randn_like = torch.rand, torch.randn_like
+    torch.rand = lambda *a, **k: t["sig_u"][cnt["i"]].to(DEV).clone()
+
+    def fake_randn_like(x, **k):
+        e = t["eps"][cnt["i"]].to(DEV).clone(); cnt["i"] += 1
+        return e
+    torch.randn_like = fake_randn_like
+    try:
+        res = finetune_lora_on_conditioning(dit, mods, t["cond"].to(DEV), t["target"].to(DEV), None, None,
+                                            num_steps=hp["num_steps"], lr=hp["lr"], warmup_steps=hp["warmup_steps"],
+                                            weight_decay=hp["weight_decay"], max_grad_norm=hp["max_grad_norm"],
+                                            device=DEV, dtype=BF16, early_stopper=None)
+    finally:
+        torch.rand, torch.randn_like = real_rand, real_randn_like
+    got, exp = torch.tensor(res["losses"]), t["losses"]
+    print("losses", got.tolist(), exp.tolist())
+    assert torch.allclose(got, exp, rtol=3e-2, atol=1e-3)
+    errs = [rel_l2(p, e.float()) for p, e in zip(params, t["final_params"])]
+    print("final adapter rel-L2 (max):", max(errs))
+    assert max(errs) < 0.06  # bf16 adapters after 5 Adam steps (sign-like updates amplify 1-ulp gradient noise)
+    assert set(res) == {"losses", "train_time", "es_check_time", "early_stopping_info"}
