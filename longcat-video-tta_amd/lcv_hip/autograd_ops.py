@@ -45,10 +45,16 @@ def clear_weight_caches():
 
 
 # --------------------------------------------------------------------------- linear
+def _pad_cols(t: torch.Tensor, width: int = 64) -> torch.Tensor:
+    out = torch.zeros((t.shape[0], width), dtype=t.dtype, device=t.device)
+    out[:, : t.shape[1]].copy_(t)
+    return out
+
+
 class _LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, epi, out_f32):
-        ctx.save_for_backward(w)
+        ctx.save_for_backward(x if w.requires_grad else None, w)
         ctx.out_f32 = out_f32
         if epi != LCV_EPI_NONE:
             raise LcvError("linear: fused activation epilogues have no backward (embedders are frozen inputs)")
@@ -56,15 +62,25 @@ class _LinearFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        (w,) = ctx.saved_tensors
+        x, w = ctx.saved_tensors
+        dyb = (dy if dy.dtype == BF16 else dy.to(BF16)).contiguous()
+        N, K = w.shape
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.gemm_nt(dyb, transposed_weight(w), None)
         if w.requires_grad:
-            raise LcvError("linear: weight gradients are out of scope (LoRA-only backward); freeze the base weight")
-        dyb = dy if dy.dtype == BF16 else dy.to(BF16)
-        N = w.shape[0]
-        if N % 64:
-            raise LcvError("linear backward: out_features must be a multiple of 64")
-        dx = ops.gemm_nt(dyb.contiguous(), transposed_weight(w), None)
-        return dx, None, None, None, None
+            # trainable weights are only supported for skinny (adapter-sized) linears: the frozen 13.6 B base never
+            # gets a dW on this path (LoRA-only backward)
+            if N <= 32:
+                dw = ops.tn_skinny(_pad_cols(dyb), x, N).to(w.dtype)
+            elif K <= 32:
+                dw = ops.tn_skinny(_pad_cols(x), dyb, K).t().contiguous().to(w.dtype)
+            else:
+                raise LcvError("linear: weight gradients of full-size linears are out of scope (LoRA-only backward); "
+                               "freeze the base weight")
+        if ctx.needs_input_grad[2]:
+            raise LcvError("linear: bias gradients are out of scope; freeze the bias")
+        return dx, dw, db, None, None
 
 
 def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], epilogue: Optional[str] = None,

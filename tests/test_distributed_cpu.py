@@ -1,0 +1,63 @@
+"""CPU, world_size 2 over gloo: the N>1 code paths (DP result gather/merge + checkpoint shards, and the sequence-parallel
+K/V all-gather bookkeeping) with real process groups."""
+import json
+import os
+import sys
+import tempfile
+from pathlib import Path
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def _worker(rank, world, port, tmp):
+    sys.path.insert(0, str(ROOT / "longcat-video-tta_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from longcat_video.parallel import data_parallel as dp
+        from longcat_video.parallel import sequence_parallel as sp
+        # ---- DP: shard 7 videos, fake per-video results, per-rank checkpoint shard, gather on rank 0
+        mine = dp.shard_indices(7, rank, world)
+        rows = [{"idx": i, "success": True, "seed": dp.seed_for_video(42, i), "rank": rank} for i in mine]
+        dp.write_checkpoint(tmp, (mine[-1] + world) if mine else rank, rows, rank=rank)
+        merged = dp.gather_results(rows)
+        if rank == 0:
+            assert [r["idx"] for r in merged] == list(range(7))
+            assert all(r["seed"] == 42 + r["idx"] for r in merged)
+            dp.write_checkpoint(tmp, dp.contiguous_next_idx(merged), merged)
+        else:
+            assert merged is None
+        # ---- SP: frame-axis shards (uneven: 5 frames over 2 ranks -> 3 + 2), all-gather of K/V rows
+        T, S, H, D = 5, 6, 2, 8
+        counts = sp.frame_shards(T, world)
+        assert counts == [3, 2] and sum(counts) == T
+        t0 = sum(counts[:rank])
+        g = torch.Generator().manual_seed(0)
+        full_k = torch.randn(1, T * S, H, D, generator=g)
+        full_v = torch.randn(1, T * S, H, D, generator=g)
+        lo, hi = t0 * S, (t0 + counts[rank]) * S
+        k_all, v_all = sp.all_gather_kv(full_k[:, lo:hi].contiguous(), full_v[:, lo:hi].contiguous(), counts, S)
+        assert torch.equal(k_all, full_k) and torch.equal(v_all, full_v)
+        assert sp.token_offset(rank, counts, S) == lo
+        # the gradient of an all-gather is a reduce-scatter: every rank contributes a full-length dK
+        dk_full = torch.full((1, T * S, H, D), float(rank + 1))
+        dk_local = sp.reduce_scatter_kv_grad(dk_full, counts, S)
+        assert dk_local.shape[1] == counts[rank] * S and torch.all(dk_local == 3.0)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world_size_2_gloo():
+    port = 29500 + os.getpid() % 2000
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_worker, args=(2, port, tmp), nprocs=2, join=True)
+        ck = json.loads((Path(tmp) / "checkpoint.json").read_text())
+        assert ck["next_idx"] == 7 and len(ck["results"]) == 7
+        assert (Path(tmp) / "checkpoint.rank1.json").exists()
