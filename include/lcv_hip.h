@@ -246,6 +246,23 @@ int lcv_adamw_step(const lcv_adam_tensor* tensors, int64_t n_tensors, int64_t to
                    const float* norm_coef, double lr, double beta1, double beta2, double eps, double weight_decay,
                    int64_t step, void* stream);
 
+/* ---- VAE decoder stages (WAN-style causal 3-D conv VAE; upstream AutoencoderKLWan.decode, contract at
+ * delta_experiment/scripts/common.py:209-221) --------------------------------------------------------------- */
+/* Causal conv3d as an implicit GEMM on the MFMA core.  x [B,Tin,Hin,Win,Cin] channels-last bf16 (Cin % 64 == 0,
+ * padded channels zero); w [Cout, kt*kh*kw*Cin] with K ordered (dt,dh,dw,cin); out [B,T,H,W,ldc], (H,W) doubled when
+ * up2x (nearest upsample folded into the gather).  kt-1 zero frames of causal padding in front, zero spatial padding.
+ * resid (nullable, laid out like out): out = resid + bf16(conv + bias).  zero_page: >= 128 bytes of device zeros. */
+int lcv_causal_conv3d(const void* x, const void* w, const void* bias, const void* resid, void* out,
+                      const void* zero_page, int64_t B, int64_t Tin, int64_t Hin, int64_t Win, int64_t Cin,
+                      int64_t Cout, int64_t ldc, int kt, int kh, int kw, int up2x, void* stream);
+/* WAN RMS_norm over channels (channels-last rows padded to Cpad): y = x / max(||x||_2, 1e-12) * sqrt(C) * gamma,
+ * optional SiLU; padding channels are written as zeros. */
+int lcv_vae_rmsnorm_silu(const void* x, const void* gamma, void* y, int64_t rows, int64_t C, int64_t Cpad,
+                         int apply_silu, void* stream);
+/* p = softmax(scale * s) row-wise; s fp32 [rows, n] (row stride ld_s), p bf16 [rows, ld_p] (columns >= n zeroed). */
+int lcv_softmax_rows(const float* s, void* p, int64_t rows, int64_t n, int64_t ld_s, int64_t ld_p, float scale,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

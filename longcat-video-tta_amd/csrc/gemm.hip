@@ -34,6 +34,13 @@ struct GemmParams {
   const float* gate;  // mod + gate_off
   int64_t rows_per_frame, mod_stride;
   int tiles_m, tiles_n;
+  // implicit-GEMM convolution mode (channels-last activations [B,Tin,Hin,Win,Cin], rows m = output pixels):
+  // K tiles run over (tap, 64-channel chunk); out-of-range taps read a zero page.
+  int cv_T, cv_H, cv_W;        // output extent (rows m = ((b*T + t)*H + h)*W + w)
+  int cv_Tin, cv_Hin, cv_Win;  // input extent
+  int cv_kt, cv_kh, cv_kw, cv_cpt;  // taps and 64-channel chunks per tap (Cin / 64)
+  int cv_up2x;                 // nearest 2x spatial upsample folded into the gather
+  const bf16_t* cv_zero;       // >= 128 bytes of zeros
 };
 
 template <int BM, int BN, int WR, int WC>
@@ -55,7 +62,7 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
   return 0.5f * x * (1.0f + tanhf(inner));
 }
 
-template <int BM, int BN, int WR, int WC, int EPI>
+template <int BM, int BN, int WR, int WC, int EPI, bool CONV>
 __global__ __launch_bounds__(WR* WC * 64) void gemm_nt_kernel(const GemmParams p) {
   using Cfg = GemmCfg<BM, BN, WR, WC>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -81,6 +88,7 @@ __global__ __launch_bounds__(WR* WC * 64) void gemm_nt_kernel(const GemmParams p
   const int ld_row = lane >> 3, ld_slot = lane & 7;
   int64_t a_row[Cfg::IA], b_row[Cfg::IB];
   int a_sw[Cfg::IA], b_sw[Cfg::IB];
+  int cv_t[Cfg::IA], cv_h[Cfg::IA], cv_w[Cfg::IA];  // conv mode: output pixel of each staged row
 #pragma unroll
   for (int t = 0; t < Cfg::IA; ++t) {
     const int row = (wave * Cfg::IA + t) * 8 + ld_row;
@@ -88,6 +96,13 @@ __global__ __launch_bounds__(WR* WC * 64) void gemm_nt_kernel(const GemmParams p
     if (g > p.M - 1) g = p.M - 1;
     a_row[t] = g;
     a_sw[t] = (ld_slot ^ ((row >> 1) & 7)) * 8;
+    if constexpr (CONV) {
+      int64_t r2 = g;
+      cv_w[t] = (int)(r2 % p.cv_W); r2 /= p.cv_W;
+      cv_h[t] = (int)(r2 % p.cv_H); r2 /= p.cv_H;
+      cv_t[t] = (int)(r2 % p.cv_T);
+      a_row[t] = r2 / p.cv_T;  // batch index
+    }
   }
 #pragma unroll
   for (int t = 0; t < Cfg::IB; ++t) {
@@ -108,10 +123,29 @@ __global__ __launch_bounds__(WR* WC * 64) void gemm_nt_kernel(const GemmParams p
     }
     unsigned char* sa = smem + buf * Cfg::STAGE_BYTES;
     unsigned char* sb = sa + Cfg::A_BYTES;
+    if constexpr (CONV) {
+      const int tap = kt / p.cv_cpt;
+      const int c0 = (kt - tap * p.cv_cpt) * 64;
+      const int dw = tap % p.cv_kw;
+      const int dh = (tap / p.cv_kw) % p.cv_kh;
+      const int dt = tap / (p.cv_kw * p.cv_kh);
 #pragma unroll
-    for (int t = 0; t < Cfg::IA; ++t) {
-      const bf16_t* src = A + a_row[t] * lda + k0 + a_sw[t];
-      __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(sa + (wave * Cfg::IA + t) * 1024), 16, 0, 0);
+      for (int t = 0; t < Cfg::IA; ++t) {
+        const int ti = cv_t[t] + dt - (p.cv_kt - 1);      // causal: kt-1 frames of zero padding in front
+        int hi = cv_h[t] + dh - (p.cv_kh >> 1);
+        int wi = cv_w[t] + dw - (p.cv_kw >> 1);
+        const bool ok = ti >= 0 && hi >= 0 && hi < p.cv_H && wi >= 0 && wi < p.cv_W;
+        if (p.cv_up2x) { hi >>= 1; wi >>= 1; }
+        const int64_t pix = ((a_row[t] * p.cv_Tin + ti) * p.cv_Hin + hi) * (int64_t)p.cv_Win + wi;
+        const bf16_t* src = ok ? (A + pix * lda + c0 + a_sw[t]) : (p.cv_zero + a_sw[t]);
+        __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(sa + (wave * Cfg::IA + t) * 1024), 16, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < Cfg::IA; ++t) {
+        const bf16_t* src = A + a_row[t] * lda + k0 + a_sw[t];
+        __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(sa + (wave * Cfg::IA + t) * 1024), 16, 0, 0);
+      }
     }
 #pragma unroll
     for (int t = 0; t < Cfg::IB; ++t) {
@@ -212,13 +246,13 @@ __global__ __launch_bounds__(WR* WC * 64) void gemm_nt_kernel(const GemmParams p
   }
 }
 
-template <int BM, int BN, int WR, int WC, int EPI>
+template <int BM, int BN, int WR, int WC, int EPI, bool CONV>
 static int launch_gemm(GemmParams& p, hipStream_t s) {
   using Cfg = GemmCfg<BM, BN, WR, WC>;
   p.tiles_m = (int)((p.M + BM - 1) / BM);
   p.tiles_n = (int)((p.N + BN - 1) / BN);
   const size_t lds = 2 * Cfg::STAGE_BYTES;
-  auto kern = gemm_nt_kernel<BM, BN, WR, WC, EPI>;
+  auto kern = gemm_nt_kernel<BM, BN, WR, WC, EPI, CONV>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
@@ -228,7 +262,7 @@ static int launch_gemm(GemmParams& p, hipStream_t s) {
     attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(Cfg::NT), lds, s, p);
-  LCV_LAUNCH_CHECK("gemm_nt");
+  LCV_LAUNCH_CHECK(CONV ? "conv_igemm" : "gemm_nt");
   return LCV_OK;
 }
 
@@ -238,8 +272,14 @@ static int dispatch_tile(GemmParams& p, hipStream_t s) {
   static const char* force = getenv("LCV_GEMM_TILE");
   bool big = p.M >= 2048 && p.N >= 1024;
   if (force) big = (force[0] == '2');
-  if (big) return launch_gemm<256, 256, 2, 4, EPI>(p, s);
-  return launch_gemm<128, 128, 2, 2, EPI>(p, s);
+  if (big) return launch_gemm<256, 256, 2, 4, EPI, false>(p, s);
+  return launch_gemm<128, 128, 2, 2, EPI, false>(p, s);
+}
+
+template <int EPI>
+static int dispatch_conv(GemmParams& p, hipStream_t s) {
+  if (p.N >= 192) return launch_gemm<256, 256, 2, 4, EPI, true>(p, s);
+  return launch_gemm<128, 128, 2, 2, EPI, true>(p, s);
 }
 
 extern "C" int lcv_gemm_nt(const void* a, const void* w, const void* bias, const void* a2, const void* w2,
@@ -262,6 +302,7 @@ extern "C" int lcv_gemm_nt(const void* a, const void* w, const void* bias, const
   p.lda = lda; p.ldw = ldw; p.lda2 = lda2; p.ldw2 = ldw2; p.ldc = ldc; p.out_f32 = out_f32;
   p.resid = (const bf16_t*)resid; p.gate = mod ? mod + gate_off : nullptr;
   p.rows_per_frame = rows_per_frame > 0 ? rows_per_frame : 1; p.mod_stride = mod_stride;
+  p.cv_zero = nullptr; p.cv_up2x = 0; p.cv_cpt = 1;
   hipStream_t s = (hipStream_t)stream;
   switch (epilogue) {
     case LCV_EPI_NONE: return dispatch_tile<LCV_EPI_NONE>(p, s);
@@ -277,6 +318,39 @@ extern "C" int lcv_gemm_nt(const void* a, const void* w, const void* bias, const
       lcv_set_error("gemm_nt: unknown epilogue %d", epilogue);
       return LCV_EINVAL;
   }
+}
+
+// ---------------------------------------------------------------------------
+// Causal 3-D convolution as an implicit GEMM on the same MFMA core (VAE decoder).
+//   x   [B, Tin, Hin, Win, Cin]  channels-last bf16, Cin % 64 == 0 (zero-padded channels)
+//   w   [Cout, kt*kh*kw*Cin]     K ordered (dt, dh, dw, cin)
+//   out [B, T, H, W, ldc] with T = Tin, (H, W) = (Hin, Win) or doubled when up2x (nearest upsample fused in the gather)
+// Temporal padding is causal (kt-1 zero frames in front), spatial padding kh/2, kw/2 zeros.
+// resid (nullable, same layout as out): out = resid + bf16(conv + bias)  (residual-block tail).
+// ---------------------------------------------------------------------------
+extern "C" int lcv_causal_conv3d(const void* x, const void* w, const void* bias, const void* resid, void* out,
+                                 const void* zero_page, int64_t B, int64_t Tin, int64_t Hin, int64_t Win,
+                                 int64_t Cin, int64_t Cout, int64_t ldc, int kt, int kh, int kw, int up2x,
+                                 void* stream) {
+  LCV_CHECK_ARG(x && w && out && zero_page, "causal_conv3d: null pointer");
+  LCV_CHECK_ARG(Cin > 0 && Cin % 64 == 0, "causal_conv3d: Cin=%ld must be a multiple of 64 (pad channels)", (long)Cin);
+  LCV_CHECK_ARG(kt >= 1 && kh >= 1 && kw >= 1 && (kh & 1) && (kw & 1), "causal_conv3d: odd spatial kernels only");
+  LCV_CHECK_ARG(ldc >= Cout, "causal_conv3d: ldc < Cout");
+  GemmParams p;
+  p.a = (const bf16_t*)x; p.w = (const bf16_t*)w; p.bias = (const bf16_t*)bias; p.a2 = nullptr; p.w2 = nullptr;
+  p.c = out;
+  p.cv_T = (int)Tin; p.cv_H = (int)(up2x ? 2 * Hin : Hin); p.cv_W = (int)(up2x ? 2 * Win : Win);
+  p.cv_Tin = (int)Tin; p.cv_Hin = (int)Hin; p.cv_Win = (int)Win;
+  p.cv_kt = kt; p.cv_kh = kh; p.cv_kw = kw; p.cv_cpt = (int)(Cin / 64); p.cv_up2x = up2x;
+  p.cv_zero = (const bf16_t*)zero_page;
+  p.M = B * p.cv_T * (int64_t)p.cv_H * p.cv_W; p.N = Cout;
+  p.nk1 = kt * kh * kw * p.cv_cpt; p.nk2 = 0;
+  p.lda = Cin; p.ldw = (int64_t)kt * kh * kw * Cin; p.lda2 = 0; p.ldw2 = 0; p.ldc = ldc; p.out_f32 = 0;
+  p.resid = (const bf16_t*)resid; p.gate = nullptr; p.rows_per_frame = 1; p.mod_stride = 0;
+  if (p.M == 0) return LCV_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (resid) return dispatch_conv<LCV_EPI_GATE_RESIDUAL>(p, s);
+  return dispatch_conv<LCV_EPI_NONE>(p, s);
 }
 
 // ---------------------------------------------------------------------------

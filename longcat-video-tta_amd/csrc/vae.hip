@@ -1,0 +1,80 @@
+// HBM-bound stages of the WAN-style causal 3-D VAE decoder on channels-last activations:
+// the channel RMS norm (+SiLU) in front of every conv, and the row softmax of the per-frame
+// single-head mid-block attention (head_dim 384: scores and PV go through the MFMA GEMM).
+#include "lcv_common.h"
+
+// y[c] = x[c] / max(||x||_2, 1e-12) * sqrt(C) * gamma[c]  (then SiLU); channels >= C (padding) are written as 0.
+// One wave per pixel row; Cpad <= 512.
+__global__ __launch_bounds__(256) void vae_rmsnorm_kernel(const bf16_t* __restrict__ x,
+                                                          const bf16_t* __restrict__ gamma,
+                                                          bf16_t* __restrict__ y, int64_t rows, int C, int Cpad,
+                                                          int apply_silu) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int c = lane * 8;
+  float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (c < Cpad) unpack8(*reinterpret_cast<const u16x8*>(x + row * Cpad + c), v);
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (c + i < C) ss += v[i] * v[i];
+  ss = wave_sum(ss);
+  const float inv = sqrtf((float)C) / fmaxf(sqrtf(ss), 1e-12f);
+  if (c < Cpad) {
+    float g[8], o[8];
+    unpack8(*reinterpret_cast<const u16x8*>(gamma + c), g);  // gamma is stored padded to Cpad
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float t = (c + i < C) ? v[i] * inv * g[i] : 0.f;
+      if (apply_silu) t = silu_f(t);
+      o[i] = t;
+    }
+    *reinterpret_cast<u16x8*>(y + row * Cpad + c) = pack8(o);
+  }
+}
+
+extern "C" int lcv_vae_rmsnorm_silu(const void* x, const void* gamma, void* y, int64_t rows, int64_t C,
+                                    int64_t Cpad, int apply_silu, void* stream) {
+  LCV_CHECK_ARG(x && gamma && y, "vae_rmsnorm_silu: null pointer");
+  LCV_CHECK_ARG(Cpad % 8 == 0 && Cpad <= 512 && C <= Cpad && C > 0, "vae_rmsnorm_silu: C=%ld Cpad=%ld unsupported", (long)C, (long)Cpad);
+  if (rows == 0) return LCV_OK;
+  hipLaunchKernelGGL(vae_rmsnorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, (const bf16_t*)gamma, (bf16_t*)y, rows, (int)C, (int)Cpad, apply_silu);
+  LCV_LAUNCH_CHECK("vae_rmsnorm_silu");
+  return LCV_OK;
+}
+
+// p[row, :] = softmax(scale * s[row, :]) ; s fp32 [rows, n] (ld_s), p bf16 [rows, ld_p]; one workgroup per row.
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, bf16_t* __restrict__ p,
+                                                           int64_t n, int64_t ld_s, int64_t ld_p, float scale) {
+  __shared__ float red[4];
+  const int64_t row = blockIdx.x;
+  const float* sr = s + row * ld_s;
+  bf16_t* pr = p + row * ld_p;
+  float mx = -INFINITY;
+  for (int64_t i = threadIdx.x; i < n; i += 256) mx = fmaxf(mx, sr[i]);
+  mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float sum = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += 256) sum += __expf((sr[i] - mx) * scale);
+  sum = wave_sum(sum);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+  __syncthreads();
+  const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
+  for (int64_t i = threadIdx.x; i < ld_p; i += 256)
+    pr[i] = (i < n) ? f2bf(__expf((sr[i] - mx) * scale) * inv) : (bf16_t)0;
+}
+
+extern "C" int lcv_softmax_rows(const float* s, void* p, int64_t rows, int64_t n, int64_t ld_s, int64_t ld_p,
+                                float scale, void* stream) {
+  LCV_CHECK_ARG(s && p && n > 0 && ld_s >= n && ld_p >= n, "softmax_rows: bad arguments");
+  if (rows == 0) return LCV_OK;
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, s, (bf16_t*)p, n,
+                     ld_s, ld_p, scale);
+  LCV_LAUNCH_CHECK("softmax_rows");
+  return LCV_OK;
+}

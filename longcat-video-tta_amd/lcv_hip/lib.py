@@ -41,6 +41,9 @@ _SIGNATURES = {
     "lcv_fm_mse": [P, P, P, P, P, I64, I64, I64, I64, I64, P],
     "lcv_grad_norm_clip": [P, I64, I64, I, F32, P, P, P],
     "lcv_adamw_step": [P, I64, I64, I, P, F64, F64, F64, F64, F64, I64, P],
+    "lcv_causal_conv3d": [P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I, I, I, I, P],
+    "lcv_vae_rmsnorm_silu": [P, P, P, I64, I64, I64, I, P],
+    "lcv_softmax_rows": [P, P, I64, I64, I64, I64, F32, P],
 }
 
 LCV_EPI_NONE, LCV_EPI_SWIGLU, LCV_EPI_GATE_RESIDUAL, LCV_EPI_GELU_TANH, LCV_EPI_SILU = 0, 1, 2, 3, 4
