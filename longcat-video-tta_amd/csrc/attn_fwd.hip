@@ -31,6 +31,31 @@ struct AttnFwdParams {
   float scale, scale_log2e;
 };
 
+#define RESCALE_THR 6.0f  // log2 units: the running max may lag by up to 2^6 before O and l are rescaled
+
+// exchange with the partner lane (l ^ 32) by ONE v_permlane32_swap: r[0] = low-half values, r[1] = high-half values in
+// every lane.  The two operands must be distinct registers (the instruction swaps halves BETWEEN them; the compiler
+// folds identical operands into one register and the swap degenerates), hence the opaque copy.
+__device__ __forceinline__ void half_pair(float v, float& lo, float& hi) {
+  // inline asm on purpose: hipcc 7.2 folds the two results of __builtin_amdgcn_permlane32_swap into one value when
+  // both operands derive from the same variable (observed: `lo + hi` became `lo + lo`).  The leading s_nop 1 covers
+  // the "VALU write -> v_permlane read" hazard (2 wait states) that the compiler does not pad inside an asm string.
+  float a = v, b = v;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 0" : "+v"(a), "+v"(b));
+  lo = a;  // [low-half value | low-half value]
+  hi = b;  // [high-half value | high-half value]
+}
+__device__ __forceinline__ float half_max(float v) {
+  float lo, hi;
+  half_pair(v, lo, hi);
+  return fmaxf(lo, hi);
+}
+__device__ __forceinline__ float half_sum(float v) {
+  float lo, hi;
+  half_pair(v, lo, hi);
+  return lo + hi;
+}
+
 // byte offset of 16-byte chunk `ch` (0..15) of row `row` in a [rows][128] bf16 tile
 __device__ __forceinline__ int tile_off(int row, int ch) {
   return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
@@ -152,15 +177,31 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnFwdPara
       }
     }
 
-    // ---- online softmax, lane-local except one cross-half exchange ----
-    float mx = fmaxf(s0[0], s1[0]);
+    // ---- online softmax, lane-local except one cross-half exchange (v_permlane32_swap, no LDS round trip) ----
+    // two independent max chains; built with -fno-honor-nans -mno-amdgpu-ieee (see lcv_hip/build.py) so fmaxf lowers to
+    // bare v_max3_f32 without a canonicalising v_max per MFMA output (scores are never NaN: inputs are finite)
+    float mxa = s0[0], mxb = s1[0];
 #pragma unroll
-    for (int e = 1; e < 16; ++e) mx = fmaxf(mx, fmaxf(s0[e], s1[e]));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.scale_log2e);  // first tile: exp2(-inf) = 0
-    const float mc = m_new * p.scale_log2e;
-    m_run = m_new;
+    for (int e = 1; e < 16; ++e) {
+      mxa = fmaxf(mxa, s0[e]);
+      mxb = fmaxf(mxb, s1[e]);
+    }
+    float mx = fmaxf(mxa, mxb);
+    mx = half_max(mx);
+    // defer-max: rescale O / l only when some query's running max grows by more than 2^RESCALE_THR; otherwise keep the
+    // old max (P <= 2^RESCALE_THR, harmless in fp32 sums and bf16 P).  The decision is wave-uniform and taken before
+    // this tile's P exists and after the previous tile's PV finished, so nothing is ever scaled twice or not at all.
+    if (__builtin_amdgcn_ballot_w64((mx - m_run) * p.scale_log2e > RESCALE_THR) != 0ull) {
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.scale_log2e);  // first tile: exp2(-inf) = 0
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
+    }
+    const float mc = m_run * p.scale_log2e;
     float psum = 0.f;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
@@ -168,11 +209,7 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnFwdPara
       s1[e] = __builtin_amdgcn_exp2f(s1[e] * p.scale_log2e - mc);
       psum += s0[e] + s1[e];
     }
-    l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int d = 0; d < 4; ++d)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
+    l_run += psum;
 
     // ---- P^T as B operand: k-step kk covers keys 16*kk .. 16*kk+15 (permuted inside the step) ----
     bf16x8 pb[4];
@@ -206,7 +243,7 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnFwdPara
   }
 
   // ---- epilogue ----
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float l_tot = half_sum(l_run);
   const float inv = 1.0f / l_tot;
   const int64_t qrow = q0 + r;
   if (qrow < p.Nq) {
