@@ -61,7 +61,7 @@ __device__ __forceinline__ int tile_off(int row, int ch) {
   return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
 }
 
-template <int NWAVES>
+template <int NWAVES, int PRIO>
 __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnFwdParams p) {
   constexpr int NT = NWAVES * 64;
   constexpr int QROWS = NWAVES * 32;
@@ -140,6 +140,7 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnFwdPara
   float m_run = -INFINITY;  // running max of the raw (unscaled) scores of this lane's query
   float l_run = 0.f;        // this lane's partial row sum (its 32 of every 64 keys)
 
+  if (PRIO == 1 && wave >= NWAVES / 2) __builtin_amdgcn_s_setprio(1);  // static priority for the younger half
   const int nt = (int)((p.Nk + 63) / 64);
   load_tile(0);
   store_tile(0);
@@ -157,6 +158,7 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnFwdPara
     f32x16 s0, s1;
 #pragma unroll
     for (int e = 0; e < 16; ++e) { s0[e] = 0.f; s1[e] = 0.f; }
+    if (PRIO == 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
       const int co = 16 * ((2 * ks + h) ^ kf);
@@ -165,6 +167,7 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnFwdPara
       s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qf[ks], s0, 0, 0, 0);
       s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qf[ks], s1, 0, 0, 0);
     }
+    if (PRIO == 2) __builtin_amdgcn_s_setprio(0);
 
     // ---- mask keys past Nk (last tile only; wave-uniform branch) ----
     if (!has_next && (p.Nk & 63)) {
@@ -222,6 +225,7 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnFwdPara
     }
 
     // ---- O^T += V^T P^T ----
+    if (PRIO == 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
@@ -238,6 +242,7 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnFwdPara
       }
     }
 
+    if (PRIO == 2) __builtin_amdgcn_s_setprio(0);
     if (has_next) store_tile(buf ^ 1);
     __syncthreads();
   }
@@ -284,17 +289,23 @@ extern "C" int lcv_attn_fwd(const void* q, const void* k, const void* v, void* o
   p.scale = scale; p.scale_log2e = scale * 1.4426950408889634f;
   constexpr int NW = 8;
   const size_t lds = 2 * 2 * 64 * 256;
-  auto kern = attn_fwd_kernel<NW>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  const char* pe = getenv("LCV_ATTN_PRIO");  // 0 none, 1 static priority for waves 4-7, 2 per MFMA cluster (A/B knob)
+  const int prio = pe ? pe[0] - '0' : 0;
+  const unsigned gx = (unsigned)((Nq + NW * 32 - 1) / (NW * 32));
+  const dim3 grid(gx, (unsigned)H, (unsigned)B);
+  auto launch = [&](auto kern) -> int {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       lcv_set_error("attn_fwd: cannot raise dynamic LDS");
       return LCV_EDEVICE;
     }
-    attr_set = true;
-  }
-  const unsigned gx = (unsigned)((Nq + NW * 32 - 1) / (NW * 32));
-  hipLaunchKernelGGL(kern, dim3(gx, (unsigned)H, (unsigned)B), dim3(NW * 64), lds, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, (hipStream_t)stream, p);
+    return LCV_OK;
+  };
+  int rc;
+  if (prio == 1) rc = launch(attn_fwd_kernel<NW, 1>);
+  else if (prio == 2) rc = launch(attn_fwd_kernel<NW, 2>);
+  else rc = launch(attn_fwd_kernel<NW, 0>);
+  if (rc != LCV_OK) return rc;
   LCV_LAUNCH_CHECK("attn_fwd");
   return LCV_OK;
 }

@@ -1,0 +1,217 @@
+"""delta-TTA ("AdaSteer") wrappers on the MI355X DiT: a learned vector added to the timestep embedding (A: one global
+delta; B: one per block group, optionally on the hidden stream, partial dim, block subset) or to the output (C).
+
+Class / method / argument names follow delta_experiment/scripts/run_delta_a.py:88-305, run_delta_b.py:99-421 and
+run_delta_c.py:82-246.  Where the reference re-implements the DiT's outer forward for training and installs hooks for
+generation, this build uses the SAME hook points for both (the reference's own Series-25 check shows the two are
+equivalent): the DiT calls `t_embedder`, each block and itself through `__call__`, gradient checkpointing stays on the
+DiT (`dit.gradient_checkpointing`), and the gradient reaches delta through the fp32 adaLN island
+(`lcv_linear_f32_smallm_bwd`) and the modulation-table gradients of `lcv_adaln_modulate_bwd` / `lcv_gate_residual_bwd`.
+The optimizer is the fused clip + AdamW in its fp32 form (delta lives in fp32: run_delta_a.py:104).
+"""
+import copy
+import math
+import time
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from lcv_hip.ops import FusedAdamWClip
+
+from .early_stopping import AnchoredEarlyStopper
+from .flow_matching import compute_flow_matching_loss_conditioned
+from .lora import _parse_target_blocks
+
+
+class _HookedWrapper(nn.Module):
+    def __init__(self, dit: nn.Module):
+        super().__init__()
+        self.dit = dit
+        for p in self.dit.parameters():
+            p.requires_grad = False
+        self._hooks: list = []
+
+    @property
+    def config(self):
+        return self.dit.config
+
+    def remove_from_dit(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+    def forward(self, hidden_states, timestep, encoder_hidden_states, encoder_attention_mask=None,
+                num_cond_latents=0, **kwargs):
+        self.apply_to_dit()
+        try:
+            return self.dit(hidden_states=hidden_states, timestep=timestep, encoder_hidden_states=encoder_hidden_states,
+                            encoder_attention_mask=encoder_attention_mask, num_cond_latents=num_cond_latents)
+        finally:
+            self.remove_from_dit()
+
+
+class DeltaAWrapper(_HookedWrapper):
+    """One delta in R^{C_t} added to the timestep embedding (t_embedder output [B*T, C_t])."""
+
+    def __init__(self, dit: nn.Module, adaln_tembed_dim: int = 512):
+        super().__init__(dit)
+        self.delta = nn.Parameter(torch.zeros(adaln_tembed_dim))
+
+    def apply_to_dit(self):
+        self.remove_from_dit()
+        delta = self.delta
+        self._hooks.append(self.dit.t_embedder.register_forward_hook(
+            lambda _m, _i, out: out + delta.unsqueeze(0).to(out.dtype)))
+
+
+class DeltaBWrapper(_HookedWrapper):
+    """Per-group deltas: group(i) = min(i // ceil(L/G), G-1); partial-dim deltas are zero-padded to the full width."""
+
+    def __init__(self, dit: nn.Module, num_groups: int = 4, adaln_tembed_dim: int = 512, hidden_size: int = 4096,
+                 delta_target: str = "timestep", delta_dim: Optional[int] = None, target_blocks: str = "all"):
+        super().__init__(dit)
+        if delta_target not in ("timestep", "hidden"):
+            raise ValueError(f"Unknown delta_target: {delta_target}")
+        self.num_groups = num_groups
+        self.num_blocks = len(dit.blocks)
+        self.delta_target = delta_target
+        self.target_block_indices = _parse_target_blocks(target_blocks, self.num_blocks)
+        full_dim = adaln_tembed_dim if delta_target == "timestep" else hidden_size
+        self._full_dim = full_dim
+        self._partial_dim = delta_dim if delta_dim is not None else full_dim
+        self.deltas = nn.ParameterList([nn.Parameter(torch.zeros(self._partial_dim)) for _ in range(num_groups)])
+        self.delta_final = nn.Parameter(torch.zeros(self._partial_dim)) if delta_target == "hidden" else None
+        per = math.ceil(self.num_blocks / num_groups)
+        self.block_to_group = [min(i // per, num_groups - 1) for i in range(self.num_blocks)]
+
+    def _pad_delta(self, dv: torch.Tensor) -> torch.Tensor:
+        if dv.shape[0] >= self._full_dim:
+            return dv
+        return F.pad(dv, (0, self._full_dim - dv.shape[0]))
+
+    def apply_to_dit(self):
+        self.remove_from_dit()
+        pad = self._pad_delta
+        for i, block in enumerate(self.dit.blocks):
+            if self.target_block_indices is not None and i not in self.target_block_indices:
+                continue
+            dv = self.deltas[self.block_to_group[i]]
+            if self.delta_target == "timestep":
+                def pre(_m, args, dv=dv):
+                    args = list(args)
+                    args[2] = args[2] + pad(dv).unsqueeze(0).unsqueeze(0).to(args[2].dtype)  # `t` is args[2]
+                    return tuple(args)
+                self._hooks.append(block.register_forward_pre_hook(pre))
+            else:
+                def post(_m, _a, out, dv=dv):
+                    e = pad(dv).unsqueeze(0).unsqueeze(0)
+                    if isinstance(out, tuple):
+                        return (out[0] + e.to(out[0].dtype),) + out[1:]
+                    return out + e.to(out.dtype)
+                self._hooks.append(block.register_forward_hook(post))
+        if self.delta_target == "hidden" and self.delta_final is not None:
+            df = self.delta_final
+
+            def final_pre(_m, args, df=df):
+                args = list(args)
+                args[0] = args[0] + pad(df).unsqueeze(0).unsqueeze(0).to(args[0].dtype)
+                return tuple(args)
+            self._hooks.append(self.dit.final_layer.register_forward_pre_hook(final_pre))
+
+
+class DeltaCWrapper(_HookedWrapper):
+    """Output bias: pred + delta_out.view(1, C_out, 1, 1, 1); no gradient flows into the DiT."""
+
+    def __init__(self, dit: nn.Module, out_channels: int = 16, delta_mode: str = "per_channel"):
+        super().__init__(dit)
+        if delta_mode != "per_channel":
+            raise ValueError(f"Unknown delta_mode: {delta_mode}")
+        self.delta_out = nn.Parameter(torch.zeros(out_channels))
+
+    def apply_to_dit(self):
+        self.remove_from_dit()
+        d = self.delta_out
+        self._hooks.append(self.dit.register_forward_hook(lambda _m, _i, out: out + d.view(1, -1, 1, 1, 1).to(out.dtype)))
+
+    def forward(self, hidden_states, timestep, encoder_hidden_states, encoder_attention_mask=None,
+                num_cond_latents=0, **kwargs):
+        with torch.no_grad():
+            pred = self.dit(hidden_states=hidden_states, timestep=timestep, encoder_hidden_states=encoder_hidden_states,
+                            encoder_attention_mask=encoder_attention_mask, num_cond_latents=num_cond_latents)
+        return pred + self.delta_out.view(1, -1, 1, 1, 1).to(pred.dtype)
+
+
+def _optimize(wrapper: nn.Module, params: List[nn.Parameter], per_param_clip: bool, cond_latents, train_latents,
+              prompt_embeds, prompt_mask, num_steps, lr, device, dtype, early_stopper, train_latents_variants):
+    groups = [[p] for p in params] if per_param_clip else [params]
+    opts = [FusedAdamWClip(g, lr=lr, betas=(0.9, 0.999), weight_decay=0.01, eps=1e-15) for g in groups]
+    if train_latents_variants is None:
+        train_latents_variants = [{"latents": train_latents, "name": "orig"}]
+
+    def _save_fn():
+        return [copy.deepcopy(p.data) for p in params]
+
+    wrapper.train()
+    losses, es_check_time = [], 0.0
+    for step in range(num_steps):
+        for o in opts:
+            o.zero_grad()
+        vi = torch.randint(0, len(train_latents_variants), (1,)).item()
+        loss = compute_flow_matching_loss_conditioned(dit=wrapper, cond_latents=cond_latents,
+                                                      target_latents=train_latents_variants[vi]["latents"],
+                                                      prompt_embeds=prompt_embeds, prompt_mask=prompt_mask,
+                                                      device=device, dtype=dtype)
+        loss.backward()
+        for o in opts:
+            if any(p.grad is not None for p in o.params):
+                o.clip_grad_norm_(1.0)
+                o.step()
+        losses.append(loss.item())
+        if early_stopper is not None:
+            t0 = time.time()
+            should_stop, es_info = early_stopper.step(step + 1, save_fn=_save_fn)
+            es_check_time += time.time() - t0
+            if should_stop:
+                print(f"  Early stopping at step {step + 1}: {es_info}")
+                break
+    es_state = None
+    if early_stopper is not None:
+        def _restore(snap):
+            for p, s in zip(params, snap):
+                p.data.copy_(s)
+        early_stopper.restore(restore_fn=_restore)
+        es_state = early_stopper.state
+    return losses, es_check_time, es_state
+
+
+def optimize_delta_a(wrapper: DeltaAWrapper, cond_latents, train_latents, prompt_embeds, prompt_mask, num_steps: int = 20,
+                     lr: float = 1e-3, device: str = "cuda", dtype: torch.dtype = torch.bfloat16,
+                     early_stopper: Optional[AnchoredEarlyStopper] = None,
+                     train_latents_variants: Optional[List[Dict]] = None) -> Dict:
+    losses, est, es_state = _optimize(wrapper, [wrapper.delta], False, cond_latents, train_latents, prompt_embeds,
+                                      prompt_mask, num_steps, lr, device, dtype, early_stopper, train_latents_variants)
+    return {"losses": losses, "delta_norm": wrapper.delta.detach().norm().item(), "es_check_time": est,
+            "early_stopping_info": es_state}
+
+
+def optimize_delta_b(wrapper: DeltaBWrapper, cond_latents, train_latents, prompt_embeds, prompt_mask, num_steps: int = 20,
+                     lr: float = 1e-3, device: str = "cuda", dtype: torch.dtype = torch.bfloat16,
+                     early_stopper: Optional[AnchoredEarlyStopper] = None,
+                     train_latents_variants: Optional[List[Dict]] = None) -> Dict:
+    params = list(wrapper.deltas) + ([wrapper.delta_final] if wrapper.delta_final is not None else [])
+    losses, est, es_state = _optimize(wrapper, params, True, cond_latents, train_latents, prompt_embeds, prompt_mask,
+                                      num_steps, lr, device, dtype, early_stopper, train_latents_variants)
+    return {"losses": losses, "delta_norms": [d.detach().norm().item() for d in wrapper.deltas], "es_check_time": est,
+            "early_stopping_info": es_state}
+
+
+def optimize_delta_c(wrapper: DeltaCWrapper, cond_latents, train_latents, prompt_embeds, prompt_mask, num_steps: int = 20,
+                     lr: float = 1e-3, device: str = "cuda", dtype: torch.dtype = torch.bfloat16,
+                     early_stopper: Optional[AnchoredEarlyStopper] = None,
+                     train_latents_variants: Optional[List[Dict]] = None) -> Dict:
+    losses, est, es_state = _optimize(wrapper, [wrapper.delta_out], False, cond_latents, train_latents, prompt_embeds,
+                                      prompt_mask, num_steps, lr, device, dtype, early_stopper, train_latents_variants)
+    return {"losses": losses, "delta_norm": wrapper.delta_out.detach().norm().item(), "es_check_time": est,
+            "early_stopping_info": es_state}

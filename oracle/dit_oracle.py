@@ -272,7 +272,7 @@ def pack_text(y_emb: torch.Tensor, mask: Optional[torch.Tensor]):
 
 
 def dit_forward(P: Dict[str, torch.Tensor], cfg: dict, hidden_states, timestep, encoder_hidden_states,
-                encoder_attention_mask=None, num_cond_latents=0, bf16: bool = True) -> torch.Tensor:
+                encoder_attention_mask=None, num_cond_latents=0, bf16: bool = True, t_delta=None) -> torch.Tensor:
     """Full forward following run_delta_a.py:134-217.  cfg: depth, num_heads, patch_size, out_channels,
     text_tokens_zero_pad."""
     rnd = bf16_round if bf16 else _id
@@ -286,6 +286,8 @@ def dit_forward(P: Dict[str, torch.Tensor], cfg: dict, hidden_states, timestep, 
     y = rnd(encoder_hidden_states.float())
     x = x_embedder(P, hs, (pt, ph, pw), rnd)
     t = t_embedder(P, ts.flatten()).reshape(B, N_t, -1)
+    if t_delta is not None:  # delta-A: run_delta_a.py:168
+        t = t + t_delta.unsqueeze(0).unsqueeze(0)
     y = y_embedder(P, y, rnd)
     mask = encoder_attention_mask
     if cfg.get("text_tokens_zero_pad", False) and mask is not None:

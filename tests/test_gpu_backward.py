@@ -283,3 +283,41 @@ def test_inner_loop_matches_reference_run():
     print("final adapter rel-L2 (max):", max(errs))
     assert max(errs) < 0.06  # bf16 adapters after 5 Adam steps (sign-like updates amplify 1-ulp gradient noise)
     assert set(res) == {"losses", "train_time", "es_check_time", "early_stopping_info"}
+
+
+def test_delta_a_gradient_and_step():
+    """delta-A: d loss / d delta through the hooked t_embedder, the fp32 adaLN island and the modulation-table gradients,
+    against torch autograd over the fp32 oracle; then one fused clip + AdamW(fp32, eps=1e-15) step vs torch.optim.AdamW."""
+    from oracle import dit_oracle as orc
+    from tta.delta import DeltaAWrapper
+    from tta.flow_matching import fm_mse_loss
+    from lcv_hip.ops import FusedAdamWClip
+    m, cfg, P = _small_dit()
+    w = DeltaAWrapper(m, adaln_tembed_dim=cfg["adaln_tembed_dim"]).to(DEV)
+    with torch.no_grad():
+        w.delta.copy_(0.05 * torch.randn(cfg["adaln_tembed_dim"], generator=torch.Generator().manual_seed(3)))
+    d0 = w.delta.detach().clone()
+    w.train()
+    B, T, H, W, L, ncond = 1, 3, 8, 8, 16, 1
+    hs = _randn(B, 16, T, H, W, seed=40); y = _randn(B, 1, L, 64, seed=41)
+    mask = torch.zeros(B, L, dtype=torch.int64); mask[:, :11] = 1
+    ts = torch.zeros(B, T); ts[:, ncond:] = 700.0
+    eps = _randn(B, 16, T - ncond, H, W, seed=42); x0 = _randn(B, 16, T - ncond, H, W, seed=43)
+    pred = w(hs.to(DEV), ts.to(BF16).to(DEV), y.to(DEV), mask.to(DEV), num_cond_latents=ncond)
+    loss = fm_mse_loss(pred, eps.to(DEV), x0.to(DEV), ncond)
+    loss.backward()
+    assert not m.t_embedder._forward_hooks            # hooks removed after the call
+    dl = d0.cpu().clone().requires_grad_(True)
+    ref = orc.dit_forward({k: v.float() for k, v in P.items()}, cfg, hs, ts.to(BF16), y, mask, ncond, bf16=False, t_delta=dl)
+    ref_loss = torch.nn.functional.mse_loss(ref[:, :, ncond:], (eps - x0).float())
+    ref_loss.backward()
+    e = rel_l2(w.delta.grad, dl.grad)
+    print("delta-A grad rel-L2:", e)
+    assert e < 3e-2
+    opt = FusedAdamWClip([w.delta], lr=1e-3, eps=1e-15)
+    g = w.delta.grad.detach().clone()
+    opt.clip_grad_norm_(1.0); opt.step()
+    pt = torch.nn.Parameter(d0.cpu().clone()); pt.grad = g.cpu().clone()
+    o2 = torch.optim.AdamW([pt], lr=1e-3, betas=(0.9, 0.999), eps=1e-15)
+    torch.nn.utils.clip_grad_norm_([pt], 1.0); o2.step()
+    assert torch.allclose(w.delta.detach().cpu(), pt.detach(), rtol=1e-6, atol=1e-9)
