@@ -1,0 +1,302 @@
+#!/usr/bin/env python3
+"""LoRA test-time adaptation runner on MI355X — same relative path, CLI flags and artifact schemas as the reference's
+`lora_experiment/scripts/run_lora_tta.py` (flags :654-741; `config.json` :855-908; per-video result keys :1174-1248;
+`checkpoint.json` = {next_idx, results}; `summary.json` :1276-1324), so `sweep_experiment/sbatch/run_sweep.sbatch:375-438`
+drives it unchanged.
+
+Inputs.  The hot path starts at latents: `--data-dir` holds `latents/*.pt` files
+({"latents": [1,16,T,h,w] normalised VAE latents of the conditioning window, "prompt_embeds": [1,1,L,4096],
+"prompt_mask": [1,L], optional "negative_embeds"/"negative_mask", "caption"}), or is `synthetic:N` for seeded synthetic
+videos (plumbing / benchmarking).  Raw-video decoding, the VAE encoder and the UMT5 text encoder are the caller-side rows
+that come next; pointing `--data-dir` at raw videos raises a per-video error that is recorded exactly the
+way the reference records failures (:1264-1271).
+
+Multi-GPU.  Launched under `torch.distributed.run` the videos are sharded `idx = rank (mod world)` (one video per
+GPU, no data-path collective), each rank writes `checkpoint.rank{r}.json`, rank 0 merges into the reference-format
+`checkpoint.json` / `summary.json`.  sigma / eps are re-seeded per video with `seed + idx` (the reference's single RNG
+stream is sequential across videos; declared deviation).
+"""
+import argparse
+import functools
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+_HERE = Path(__file__).resolve()
+_PKG = _HERE.parents[2]
+if str(_PKG) not in sys.path:
+    sys.path.insert(0, str(_PKG))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from longcat_video.parallel import data_parallel as dp  # noqa: E402
+from tta import cli_args as C  # noqa: E402
+from tta.early_stopping import add_early_stopping_args, build_early_stopper_from_args  # noqa: E402
+from tta.inner_loop import finetune_lora_on_conditioning  # noqa: E402
+from tta.latent_split import _estimate_latent_len, num_frames_valid, split_tta_latents  # noqa: E402
+from tta.lora import (count_lora_parameters, get_lora_parameters, inject_lora_into_dit, reset_lora_weights,  # noqa: E402
+                      save_lora_weights)
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description="LoRA TTA for LongCat-Video (MI355X)")
+    p.add_argument("--checkpoint-dir", type=str, required=True, help="checkpoint dir, or synthetic[:depth] for random init")
+    p.add_argument("--data-dir", type=str, required=True)
+    p.add_argument("--output-dir", type=str, required=True)
+    p.add_argument("--restart", action="store_true")
+    p.add_argument("--lora-rank", type=int, default=8)
+    p.add_argument("--lora-alpha", type=float, default=16.0)
+    p.add_argument("--lora-dropout", type=float, default=0.0)
+    p.add_argument("--target-ffn", action="store_true")
+    p.add_argument("--target-modules", type=str, default="qkv,proj")
+    p.add_argument("--lora-target-blocks", type=str, default="all")
+    p.add_argument("--use-builtin-lora", action="store_true")
+    p.add_argument("--save-lora-weights", action="store_true")
+    p.add_argument("--learning-rate", type=float, default=2e-4)
+    p.add_argument("--num-steps", type=int, default=20)
+    p.add_argument("--warmup-steps", type=int, default=3)
+    p.add_argument("--weight-decay", type=float, default=0.01)
+    p.add_argument("--max-grad-norm", type=float, default=1.0)
+    p.add_argument("--max-videos", type=int, default=100)
+    p.add_argument("--seed", type=int, default=42)
+    p.add_argument("--device", type=str, default="cuda")
+    p.add_argument("--num-cond-frames", type=int, default=2)
+    p.add_argument("--num-frames", type=int, default=16)
+    p.add_argument("--gen-start-frame", type=int, default=32)
+    p.add_argument("--num-inference-steps", type=int, default=50)
+    p.add_argument("--guidance-scale", type=float, default=4.0)
+    p.add_argument("--resolution", type=str, default="480p")
+    p.add_argument("--skip-generation", action="store_true")
+    p.add_argument("--no-save-videos", action="store_true")
+    p.add_argument("--batch-videos", type=int, default=1)
+    p.add_argument("--batch-method", type=str, default="similarity", choices=["similarity", "sequential"])
+    p.add_argument("--retrieval-pool-dir", type=str, default=None)
+    add_early_stopping_args(p)
+    C.add_augmentation_args(p)
+    C.add_tta_frame_args(p)
+    C.add_caption_guard_args(p)
+    C.add_caption_override_args(p)
+    C.add_feature_frame_guard_args(p)
+    C.add_online_eval_args(p)
+    C.add_clip_gate_args(p)
+    return p
+
+
+def load_components(args, device):
+    from longcat_video.modules.longcat_video_dit import LongCatVideoTransformer3DModel
+    from longcat_video.modules.scheduling_flow_match_euler_discrete import FlowMatchEulerDiscreteScheduler
+    from longcat_video.pipeline_longcat_video import LongCatVideoPipeline
+    ck = args.checkpoint_dir
+    if ck.startswith("synthetic"):
+        kw = {}
+        if ":" in ck:  # synthetic:depth[:hidden] — reduced sizes are for plumbing tests only
+            parts = ck.split(":")[1:]
+            kw["depth"] = int(parts[0])
+            if len(parts) > 1:
+                kw.update(hidden_size=int(parts[1]), num_heads=int(parts[1]) // 128)
+            if len(parts) > 2:
+                kw.update(caption_channels=int(parts[2]))
+        dit = LongCatVideoTransformer3DModel(device=device, dtype=torch.bfloat16, **kw).init_synthetic_(1234)
+        sched, vae = FlowMatchEulerDiscreteScheduler(), None
+    else:
+        dit = LongCatVideoTransformer3DModel.from_pretrained(ck, subfolder="dit", cp_split_hw=[1, 1],
+                                                             enable_flashattn2=True, torch_dtype=torch.bfloat16).to(device)
+        sched = FlowMatchEulerDiscreteScheduler.from_pretrained(ck, subfolder="scheduler")
+        from longcat_video.modules.autoencoder_kl_wan import AutoencoderKLWan
+        vae = AutoencoderKLWan.from_pretrained(ck, subfolder="vae", torch_dtype=torch.bfloat16).to(device)
+    pipe = LongCatVideoPipeline(vae=vae, scheduler=sched, dit=dit)
+    pipe.device = torch.device(device)
+    return dit, pipe
+
+
+def list_eval_entries(args, dit):
+    d = args.data_dir
+    if d.startswith("synthetic"):
+        n = int(d.split(":")[1]) if ":" in d else 4
+        return [{"kind": "synthetic", "name": f"synthetic_{i:04d}", "path": f"synthetic://{i}", "seed": 1000 + i}
+                for i in range(min(n, args.max_videos))]
+    lat = Path(d) / "latents"
+    if lat.is_dir():
+        files = sorted(lat.glob("*.pt"))[: args.max_videos]
+        return [{"kind": "latents", "name": f.stem, "path": str(f)} for f in files]
+    vids = sorted(p for p in Path(d).rglob("*") if p.suffix.lower() in (".mp4", ".avi", ".mkv"))[: args.max_videos]
+    return [{"kind": "video", "name": v.stem, "path": str(v)} for v in vids]
+
+
+def load_entry(entry, args, dit, device):
+    h, w = {"480p": (60, 104), "720p": (90, 160)}[args.resolution]
+    if entry["kind"] == "synthetic":
+        T = _estimate_latent_len(args.tta_total_frames)
+        g = torch.Generator(device=device).manual_seed(entry["seed"])
+        cy = dit.config.caption_channels
+        lat = torch.randn((1, dit.config.in_channels, T, h, w), generator=g, device=device).to(torch.bfloat16)
+        pe = torch.randn((1, 1, 512, cy), generator=g, device=device).to(torch.bfloat16)
+        pm = torch.zeros((1, 512), dtype=torch.int64, device=device); pm[:, :77] = 1
+        return dict(latents=lat, prompt_embeds=pe, prompt_mask=pm, negative_embeds=torch.zeros_like(pe), negative_mask=pm,
+                    caption="synthetic")
+    if entry["kind"] == "latents":
+        blob = torch.load(entry["path"], map_location=device)
+        blob.setdefault("caption", "")
+        return blob
+    raise NotImplementedError("raw-video input needs the PyAV decode + VAE-encode + UMT5 rows that precede the hot path "
+                              "(SURVEY §8(f)); pre-encode to <data-dir>/latents/*.pt")
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    C.normalize_tta_frame_args(args)
+    C.validate_tta_feature_budget(args, context="lora_tta")
+    C.reject_out_of_scope(args)
+    if args.use_builtin_lora:
+        raise NotImplementedError("--use-builtin-lora: use the reference's own injector on the drop-in DiT "
+                                  "(longcat_video.modules.lora_utils.LoRAModule); this runner ships the fused adapters")
+    if args.batch_videos != 1:
+        raise NotImplementedError("retrieval-augmented batch TTA needs the sentence-transformer pool (SURVEY §2 #16)")
+
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl")
+    device = f"cuda:{local_rank}" if args.device.startswith("cuda") else args.device
+    torch.manual_seed(args.seed)
+    np.random.seed(args.seed)
+    os.makedirs(args.output_dir, exist_ok=True)
+    videos_dir = os.path.join(args.output_dir, "videos"); os.makedirs(videos_dir, exist_ok=True)
+    lora_dir = os.path.join(args.output_dir, "lora_weights")
+    if args.save_lora_weights:
+        os.makedirs(lora_dir, exist_ok=True)
+
+    prior = None if args.restart else dp.load_checkpoint(args.output_dir, rank if world > 1 else None)
+    all_results = prior["results"] if prior else []
+    done = {r["idx"] for r in all_results}
+
+    dit, pipe = load_components(args, device)
+    from torch.utils.checkpoint import checkpoint
+    dit.gradient_checkpointing = True                      # run_lora_tta.py:806-811
+    dit._gradient_checkpointing_func = functools.partial(checkpoint, use_reentrant=False)
+    for p in dit.parameters():                             # :813-815
+        p.requires_grad = False
+    target_modules = [m.strip() for m in args.target_modules.split(",") if m.strip()]
+    lora_modules = inject_lora_into_dit(dit, rank=args.lora_rank, alpha=args.lora_alpha, dropout=args.lora_dropout,
+                                        target_modules=target_modules, target_ffn=args.target_ffn,
+                                        target_blocks=args.lora_target_blocks)
+    counts = count_lora_parameters(lora_modules)
+    if rank == 0:
+        exp_config = {
+            "method": "lora_tta_custom",
+            "lora": {"implementation": "custom", "rank": args.lora_rank, "alpha": args.lora_alpha,
+                     "dropout": args.lora_dropout, "target_modules": target_modules,
+                     "target_blocks": args.lora_target_blocks, "target_ffn": args.target_ffn,
+                     "num_modules": len(lora_modules), "trainable_params": counts["trainable"]},
+            "training": {"learning_rate": args.learning_rate, "num_steps": args.num_steps,
+                         "warmup_steps": args.warmup_steps, "weight_decay": args.weight_decay,
+                         "max_grad_norm": args.max_grad_norm},
+            "generation": {"num_cond_frames": args.num_cond_frames, "num_frames": args.num_frames,
+                           "num_inference_steps": args.num_inference_steps, "guidance_scale": args.guidance_scale,
+                           "resolution": args.resolution},
+            "seed": args.seed, "max_videos": args.max_videos, "clip_gate_enabled": args.clip_gate_enabled,
+            "clip_gate_threshold": args.clip_gate_threshold, "clip_gate_backend": args.clip_gate_backend,
+            "clip_gate_model": args.clip_gate_model, "clip_gate_sample_frames": args.clip_gate_sample_frames,
+            "clip_gate_aggregation": args.clip_gate_aggregation,
+            "clip_gate_sampling_mode": "late_only" if args.clip_gate_late_only else args.clip_gate_sampling_mode,
+            "clip_gate_late_fraction": args.clip_gate_late_fraction, "clip_gate_log_only": args.clip_gate_log_only,
+            "clip_gate_fail_open": args.clip_gate_fail_open,
+            "runtime": {"backend": "mi355x-hip", "world_size": world},
+        }
+        with open(os.path.join(args.output_dir, "config.json"), "w") as f:
+            json.dump(exp_config, f, indent=2)
+
+    entries = list_eval_entries(args, dit)
+    my_idx = [i for i in dp.shard_indices(len(entries), rank, world) if i not in done]
+    early_stopper = build_early_stopper_from_args(args)
+    n_ctx_lat = _estimate_latent_len(args.tta_context_frames)
+
+    for idx in my_idx:
+        e = entries[idx]
+        try:
+            torch.manual_seed(dp.seed_for_video(args.seed, idx))
+            blob = load_entry(e, args, dit, device)
+            cond, train, val = split_tta_latents(blob["latents"], n_ctx_lat, args.es_holdout_fraction)
+            reset_lora_weights(lora_modules)
+            es = early_stopper if (early_stopper is not None and val is not None) else None
+            if es is not None:
+                params = get_lora_parameters(lora_modules)
+                es.setup(dit, cond, val, blob["prompt_embeds"], blob["prompt_mask"], device=device, dtype=torch.bfloat16,
+                         video_id=e["name"], save_fn=lambda: [p.data.clone() for p in params])
+            tr = finetune_lora_on_conditioning(dit, lora_modules, cond, train, blob["prompt_embeds"], blob["prompt_mask"],
+                                               num_steps=args.num_steps, lr=args.learning_rate,
+                                               warmup_steps=args.warmup_steps, weight_decay=args.weight_decay,
+                                               max_grad_norm=args.max_grad_norm, device=device, dtype=torch.bfloat16,
+                                               early_stopper=es)
+            result = {"idx": idx, "video_name": e["name"], "video_path": e["path"], "caption": blob.get("caption", ""),
+                      "train_time": tr["train_time"], "es_check_time": tr.get("es_check_time", 0.0),
+                      "final_loss": tr["losses"][-1] if tr["losses"] else None, "num_train_steps": len(tr["losses"]),
+                      "batch_size": 1, "num_neighbors": 0, "early_stopping_info": tr.get("early_stopping_info"),
+                      "success": True}
+            gen_time = 0.0
+            if not args.skip_generation:
+                t0 = time.time()
+                n_valid = num_frames_valid(args.num_frames)
+                T_lat = _estimate_latent_len(n_valid)
+                ncl = _estimate_latent_len(args.num_cond_frames)
+                g = torch.Generator(device=device).manual_seed(args.seed + idx)
+                lat = torch.randn((1,) + tuple(blob["latents"].shape[1:2]) + (T_lat,) + tuple(blob["latents"].shape[3:]),
+                                  generator=g, device=device, dtype=torch.float32)
+                lat[:, :, :ncl] = blob["latents"][:, :, -ncl:].float()
+                out = pipe.denoise(lat, blob["prompt_embeds"], blob["prompt_mask"], blob.get("negative_embeds"),
+                                   blob.get("negative_mask"), num_cond_latents=ncl,
+                                   num_inference_steps=args.num_inference_steps, guidance_scale=args.guidance_scale,
+                                   use_kv_cache=True)
+                if pipe.vae is not None and not args.no_save_videos:
+                    frames = pipe._decode_to_numpy(out)
+                    np.save(os.path.join(videos_dir, f"{e['name']}_lora.npy"), (frames * 255).astype(np.uint8))
+                    result["output_path"] = os.path.join(videos_dir, f"{e['name']}_lora.npy")
+                torch.cuda.synchronize()
+                gen_time = time.time() - t0
+                result["gen_time"] = gen_time
+            result["total_time"] = tr["train_time"] + gen_time
+            if args.save_lora_weights:
+                save_lora_weights(lora_modules, os.path.join(lora_dir, f"{e['name']}_lora.pt"))
+            print(f"  [{idx}] {e['name']}: train {tr['train_time']:.1f}s loss {result['final_loss']}"
+                  + (f" gen {gen_time:.1f}s" if not args.skip_generation else ""))
+            all_results.append(result)
+        except Exception as ex:  # recorded and skipped, like the reference (:1264-1271)
+            import traceback
+            print(f"  ERROR: {ex}")
+            traceback.print_exc()
+            all_results.append({"idx": idx, "video_name": e["name"], "video_path": e["path"], "error": str(ex),
+                                "success": False})
+        dp.write_checkpoint(args.output_dir, idx + world, all_results, rank=rank if world > 1 else None)
+
+    merged = dp.gather_results(all_results) if world > 1 else dp.merge_results([all_results])
+    if rank == 0:
+        ok = [r for r in merged if r.get("success", False)]
+        mean = lambda k: float(np.mean([r.get(k, 0.0) or 0.0 for r in ok])) if ok else 0
+        summary = {"method": "lora_tta", "lora_rank": args.lora_rank, "lora_alpha": args.lora_alpha,
+                   "learning_rate": args.learning_rate, "num_steps": args.num_steps,
+                   "num_cond_frames": args.num_cond_frames, "num_frames": args.num_frames,
+                   "gen_start_frame": args.gen_start_frame, "batch_videos": args.batch_videos,
+                   "retrieval_pool_dir": args.retrieval_pool_dir, "num_videos": len(merged), "num_successful": len(ok),
+                   "num_failed": len(merged) - len(ok), "avg_train_time": mean("train_time"),
+                   "avg_clip_gate_eval_time": 0, "avg_es_check_time": mean("es_check_time"),
+                   "avg_gen_time": mean("gen_time"), "avg_total_time": mean("total_time"),
+                   "avg_final_loss": float(np.mean([r["final_loss"] for r in ok if r.get("final_loss") is not None])) if ok else 0,
+                   "clip_gate_enabled": False, "clip_gate_stats": {"skip_rate": 0.0, "num_skipped": 0, "num_scored": 0},
+                   "results": merged}
+        dp.write_checkpoint(args.output_dir, dp.contiguous_next_idx(merged), merged)
+        with open(os.path.join(args.output_dir, "summary.json"), "w") as f:
+            json.dump(summary, f, indent=2, default=str)
+        print(f"LoRA TTA complete: {len(ok)}/{len(merged)} videos")
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
