@@ -29,6 +29,7 @@ WORKLOADS = {  # name: (T_lat, h, w, description)
     "K1": (5, 32, 32, "16x256x256 clip (17 frames -> 5 latent frames, 1 280 tokens)"),
     "K2": (13, 60, 104, "49x480p (13 latent frames, 20 280 tokens)"),
     "K3": (13, 90, 160, "49x720p (13 latent frames, 46 800 tokens)"),
+    "K5": (31, 60, 104, "121x480p long clip (31 latent frames, 48 360 tokens)"),
 }
 MFMA_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
 
@@ -43,6 +44,9 @@ def parse():
     ap.add_argument("--guidance-scale", type=float, default=4.0)
     ap.add_argument("--depth", type=int, default=48, help="debug only: anything but 48 is not the named model")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--parallelism", default="dp", choices=["dp", "sp"],
+                    help="dp: one independent video per GPU (weak scaling, default); sp: ONE video, latent frames sharded "
+                         "over the GPUs with an RCCL K/V all-gather per attention layer (strong scaling, config K5)")
     return ap.parse_args()
 
 
@@ -122,9 +126,12 @@ def main():
     dit.init_synthetic_(seed=1234)
     pipe = LongCatVideoPipeline(scheduler=FlowMatchEulerDiscreteScheduler(), dit=dit)
     pipe.device = dev
+    sp = args.parallelism == "sp" and world > 1
+    if sp:
+        dit.enable_sequence_parallel(None)
 
     # synthetic inputs: one independent video per rank (data parallel), seeded per rank
-    g = torch.Generator(device=dev).manual_seed(42 + rank)
+    g = torch.Generator(device=dev).manual_seed(42 + (0 if sp else rank))  # sp: every rank holds the same video
     latents = torch.randn((1, 16, T, h, w), generator=g, device=dev, dtype=torch.float32)
     g2 = torch.Generator(device=dev).manual_seed(43)
     pe = torch.randn((1, 1, 512, 4096), generator=g2, device=dev, dtype=torch.float32).to(torch.bfloat16)
@@ -161,7 +168,7 @@ def main():
 
     sec_per_step = elapsed / args.steps
     per_gpu = T / (args.num_inference_steps * sec_per_step)
-    value = per_gpu * world
+    value = per_gpu if sp else per_gpu * world
 
     # roofline of the dominant kernel (self-attention forward launches only: Nq = Nk = all tokens)
     big = [(s.elapsed_time(e), f) for (s, e, f, nq, nk) in prof if nq == nk]
@@ -178,12 +185,12 @@ def main():
     line = {
         "metric": "denoised latent frames/sec (49x720p, 50-step CFG denoise)", "value": value,
         "unit": "latent frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": sec_per_step * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": sec_per_step * 1e3, "higher_is_better": True, "scaling": "strong" if sp else "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"{args.workload}: {desc}; DiT 48 blocks x 4096 hidden, CFG {args.guidance_scale}, "
                                f"{args.num_inference_steps}-step flow-match Euler, no conditioning frames",
-                   "depth": args.depth, "tokens": T * (h // 2) * (w // 2), "parallelism": f"dp{world}",
-                   "latent_frame_steps_per_s": T * world / sec_per_step,
+                   "depth": args.depth, "tokens": T * (h // 2) * (w // 2), "parallelism": f"{'sp' if sp else 'dp'}{world}",
+                   "latent_frame_steps_per_s": T * (1 if sp else world) / sec_per_step,
                    "wall_clock_per_video_s_extrapolated": sec_per_step * args.num_inference_steps},
         "roofline": {"kernel": "attn_fwd_kernel<8>", "bound": "mfma", "achieved": achieved, "peak": MFMA_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": traffic,

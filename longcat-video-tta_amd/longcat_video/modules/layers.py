@@ -124,6 +124,9 @@ class Attention(nn.Module):
         B, N, C = x.shape
         H, D = self.num_heads, self.head_dim
         qkv = self.qkv(x).view(B, N, 3, H, D)
+        sp = getattr(self, "_sp", None)
+        if sp is not None:
+            return self._forward_sequence_parallel(qkv, shape, num_cond_latents, sp)
         cs = self.rope_3d.table(shape, x.device)
         n_cond = 0
         if num_cond_latents is not None and num_cond_latents > 0:
@@ -134,6 +137,20 @@ class Attention(nn.Module):
         if return_kv:
             return out, kv
         return out
+
+    def _forward_sequence_parallel(self, qkv, shape, num_cond_latents, sp):
+        """Frame-sharded tokens: RoPE at GLOBAL positions, all-gather of K/V (post-norm, post-RoPE), local-Q x full-KV."""
+        if torch.is_grad_enabled() and qkv.requires_grad:
+            raise NotImplementedError("sequence-parallel attention is an inference path this round (dK/dV reduce-scatter next)")
+        if num_cond_latents:
+            raise NotImplementedError("sequence parallelism with conditioning frames: shard the noise frames, replicate cond K/V (next)")
+        B, N, _, H, D = qkv.shape
+        cs = self.rope_3d.table((sp.num_frames, shape[1], shape[2]), qkv.device)
+        q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+        ops.qknorm_rope(q, k, None, q, k, None, self.q_norm.weight, self.k_norm.weight, cs, sp.token_offset, self.q_norm.eps)
+        k_full, v_full = sp.all_gather_kv(k.contiguous(), v.contiguous())
+        o, _ = ops.attention(q, k_full, v_full, self.scale)
+        return self.proj(o.view(B, N, H * D))
 
     def forward_with_kv_cache(self, x, shape=None, num_cond_latents=None, kv_cache=None):
         """Denoise step over the noise tokens only; cached (post-norm, post-RoPE) cond K / V lead the keys."""

@@ -70,6 +70,7 @@ class LongCatVideoTransformer3DModel(nn.Module):
         self.final_layer = FinalLayer_FP32(c["hidden_size"], num_patch, c["out_channels"], c["adaln_tembed_dim"], **kw)
         self.gradient_checkpointing = False
         self._gradient_checkpointing_func = None
+        self._sp_group = None
 
     # ------------------------------------------------------------------ loading
     @classmethod
@@ -127,9 +128,46 @@ class LongCatVideoTransformer3DModel(nn.Module):
         y_seqlens = [encoder_hidden_states.shape[2]] * encoder_hidden_states.shape[0]
         return encoder_hidden_states.squeeze(1).reshape(1, -1, hidden), y_seqlens
 
+    # ------------------------------------------------------------------ sequence parallelism (frame axis)
+    def enable_sequence_parallel(self, group=None):
+        """Shard the latent frames of every forward over `group` (RCCL over xGMI): per-token work is local, each
+        attention layer all-gathers K and V.  `disable_sequence_parallel()` restores the single-GPU path."""
+        self._sp_group = (group,)
+
+    def disable_sequence_parallel(self):
+        self._sp_group = None
+        for b in self.blocks:
+            b.attn._sp = None
+
+    def _forward_sp(self, hidden_states, timestep, encoder_hidden_states, encoder_attention_mask, num_cond_latents):
+        from ..parallel.sequence_parallel import SPContext
+        if num_cond_latents:
+            raise NotImplementedError("sequence parallelism with conditioning frames is not built yet")
+        B, _, T, H, W = hidden_states.shape
+        N_h, N_w = H // self.patch_size[1], W // self.patch_size[2]
+        sp = SPContext(T // self.patch_size[0], N_h * N_w, self._sp_group[0])
+        if len(timestep.shape) == 1:
+            timestep = timestep.unsqueeze(1).expand(-1, T)
+        for b in self.blocks:
+            b.attn._sp = sp
+        try:
+            self._sp_group, saved = None, self._sp_group      # the local call below is the plain path on this shard
+            local = self.forward(hidden_states[:, :, sp.t0:sp.t1].contiguous(), timestep[:, sp.t0:sp.t1].contiguous(),
+                                 encoder_hidden_states, encoder_attention_mask, 0)
+        finally:
+            self._sp_group = saved
+            for b in self.blocks:
+                b.attn._sp = None
+        return sp.gather_frames(local)
+
     # ------------------------------------------------------------------ forward
     def forward(self, hidden_states, timestep, encoder_hidden_states, encoder_attention_mask=None,
                 num_cond_latents=0, return_kv=False, kv_cache_dict=None, skip_crs_attn=False, **kwargs):
+        if getattr(self, "_sp_group", None) is not None:
+            if return_kv or kv_cache_dict is not None:
+                raise NotImplementedError("KV cache under sequence parallelism is not built yet")
+            return self._forward_sp(hidden_states, timestep, encoder_hidden_states, encoder_attention_mask,
+                                    num_cond_latents)
         B, _, T, H, W = hidden_states.shape
         N_t, N_h, N_w = T // self.patch_size[0], H // self.patch_size[1], W // self.patch_size[2]
         if len(timestep.shape) == 1:

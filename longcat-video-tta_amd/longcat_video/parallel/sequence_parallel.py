@@ -52,3 +52,43 @@ def reduce_scatter_kv_grad(d_full: torch.Tensor, counts: List[int], tokens_per_f
     dist.all_reduce(d, op=dist.ReduceOp.SUM, group=group)   # uneven shards: all-reduce + slice (reduce_scatter needs equal parts)
     lo = sum(counts[:rank]) * tokens_per_frame
     return d[:, lo:lo + counts[rank] * tokens_per_frame].contiguous()
+
+
+class SPContext:
+    """Frame-axis shard of one forward pass: which latent frames / tokens this rank owns and the K/V exchange.
+
+    `group` is a torch.distributed process group ("nccl" = RCCL over xGMI in production).  With the gloo backend
+    (CPU tests, or several ranks sharing one GPU) device tensors are staged through host memory for the collective."""
+
+    def __init__(self, num_frames: int, tokens_per_frame: int, group=None):
+        import torch.distributed as dist
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.S = tokens_per_frame
+        self.counts = frame_shards(num_frames, self.world)
+        self.t0 = sum(self.counts[: self.rank])
+        self.t1 = self.t0 + self.counts[self.rank]
+        self.num_frames = num_frames
+        self._host_staged = dist.get_backend(group) == "gloo"
+
+    @property
+    def token_offset(self) -> int:
+        return self.t0 * self.S
+
+    def _coll(self, fn, x: torch.Tensor) -> torch.Tensor:
+        if self._host_staged and x.is_cuda:
+            return fn(x.cpu()).to(x.device)
+        return fn(x)
+
+    def all_gather_kv(self, k_local: torch.Tensor, v_local: torch.Tensor):
+        k = self._coll(lambda t: _gather_rows(t, self.counts, self.S, self.group), k_local)
+        v = self._coll(lambda t: _gather_rows(t, self.counts, self.S, self.group), v_local)
+        return k, v
+
+    def gather_frames(self, x_local: torch.Tensor) -> torch.Tensor:
+        """[B, C, T_local, H, W] -> [B, C, T, H, W] on every rank."""
+        B, C, Tl, H, W = x_local.shape
+        rows = x_local.permute(0, 2, 1, 3, 4).reshape(B, Tl, C * H * W).contiguous()
+        full = self._coll(lambda t: _gather_rows(t, self.counts, 1, self.group), rows)
+        return full.view(B, self.num_frames, C, H, W).permute(0, 2, 1, 3, 4).contiguous()
