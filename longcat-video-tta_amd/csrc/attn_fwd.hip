@@ -29,6 +29,7 @@ struct AttnFwdParams {
   int H;
   int64_t q_sb, q_sn, q_sh, k_sb, k_sn, k_sh, v_sb, v_sn, v_sh, o_sb, o_sn, o_sh;
   float scale, scale_log2e;
+  int gx, xcd_remap;  // q-blocks per (b,h); head-per-XCD block order when (B*H) % 8 == 0
 };
 
 #define RESCALE_THR 6.0f  // log2 units: the running max may lag by up to 2^6 before O and l are rescaled
@@ -74,9 +75,22 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnFwdPara
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
-  const int head = blockIdx.y;
-  const int64_t b = blockIdx.z;
-  const int64_t q0 = (int64_t)blockIdx.x * QROWS + wave * 32;
+  // Block order (speed only, never correctness): workgroup ids are dealt round-robin over the 8 XCDs, so with the
+  // remap every XCD walks the q-blocks of ITS OWN (batch, head) pairs and that head's K/V (24 MB at K3) streams
+  // through one 4 MiB L2 instead of eight.
+  int qb, head;
+  int64_t b;
+  if (p.xcd_remap) {
+    const int id = blockIdx.x;
+    const int xcd = id & 7, j = id >> 3;
+    const int pair = (j / p.gx) * 8 + xcd;
+    qb = j - (j / p.gx) * p.gx;
+    head = pair % p.H;
+    b = pair / p.H;
+  } else {
+    qb = blockIdx.x; head = blockIdx.y; b = blockIdx.z;
+  }
+  const int64_t q0 = (int64_t)qb * QROWS + wave * 32;
 
   const bf16_t* kbase = p.k + b * p.k_sb + (int64_t)head * p.k_sh;
   const bf16_t* vbase = p.v + b * p.v_sb + (int64_t)head * p.v_sh;
@@ -292,7 +306,10 @@ extern "C" int lcv_attn_fwd(const void* q, const void* k, const void* v, void* o
   const char* pe = getenv("LCV_ATTN_PRIO");  // 0 none, 1 static priority for waves 4-7, 2 per MFMA cluster (A/B knob)
   const int prio = pe ? pe[0] - '0' : 0;
   const unsigned gx = (unsigned)((Nq + NW * 32 - 1) / (NW * 32));
-  const dim3 grid(gx, (unsigned)H, (unsigned)B);
+  const char* xe = getenv("LCV_ATTN_XCD");  // A/B knob: 0 disables the head-per-XCD block order
+  p.gx = (int)gx;
+  p.xcd_remap = ((B * H) % 8 == 0 && gx >= 8 && !(xe && xe[0] == '0')) ? 1 : 0;
+  const dim3 grid = p.xcd_remap ? dim3(gx * (unsigned)(H * B)) : dim3(gx, (unsigned)H, (unsigned)B);
   auto launch = [&](auto kern) -> int {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       lcv_set_error("attn_fwd: cannot raise dynamic LDS");
