@@ -62,7 +62,9 @@ __device__ __forceinline__ int tile_off(int row, int ch) {
   return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
 }
 
-template <int NWAVES, int PRIO>
+// XATTN only names the instantiation used for the short-KV text cross-attention (Nk <= 512) so that profiles list it
+// separately from the self-attention launches (the dominant kernel); the code path is the same.
+template <int NWAVES, int PRIO, bool XATTN>
 __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnFwdParams p) {
   constexpr int NT = NWAVES * 64;
   constexpr int QROWS = NWAVES * 32;
@@ -319,9 +321,10 @@ extern "C" int lcv_attn_fwd(const void* q, const void* k, const void* v, void* o
     return LCV_OK;
   };
   int rc;
-  if (prio == 1) rc = launch(attn_fwd_kernel<NW, 1>);
-  else if (prio == 2) rc = launch(attn_fwd_kernel<NW, 2>);
-  else rc = launch(attn_fwd_kernel<NW, 0>);
+  if (Nk <= 512) rc = launch(attn_fwd_kernel<NW, 0, true>);
+  else if (prio == 1) rc = launch(attn_fwd_kernel<NW, 1, false>);
+  else if (prio == 2) rc = launch(attn_fwd_kernel<NW, 2, false>);
+  else rc = launch(attn_fwd_kernel<NW, 0, false>);
   if (rc != LCV_OK) return rc;
   LCV_LAUNCH_CHECK("attn_fwd");
   return LCV_OK;

@@ -62,6 +62,26 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
   return 0.5f * x * (1.0f + tanhf(inner));
 }
 
+// Workgroup id -> output tile.  Ids that share an XCD (id % 8, observed round-robin dealing; speed only) get a contiguous run
+// of the tile sequence, and the sequence itself is "grouped": GROUP_M consecutive tile rows are walked column by column,
+// so the ~32 workgroups resident on one XCD cover an 8 x 4 block of tiles and share 8 A panels + 4 W panels in that
+// XCD's L2 instead of 32 A panels + 1 W panel.
+__device__ __forceinline__ void gemm_tile_coords(const GemmParams& p, int& tm, int& tn) {
+  constexpr int GROUP_M = 8;
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int orig = blockIdx.x;
+  const int xcd = orig & 7;
+  const int q = nwg >> 3, r8 = nwg & 7;
+  const int pid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (orig >> 3);
+  const int per_group = GROUP_M * p.tiles_n;
+  const int group = pid / per_group;
+  const int first_m = group * GROUP_M;
+  const int gsz = (p.tiles_m - first_m) < GROUP_M ? (p.tiles_m - first_m) : GROUP_M;
+  const int in_group = pid - group * per_group;
+  tm = first_m + in_group % gsz;
+  tn = in_group / gsz;
+}
+
 // ---- shared epilogue: acc[i][j][e] is C[row = (e&3)+8*(e>>2)+4*h][col = lane&31] of its 32x32 tile ----
 template <int BM, int BN, int WR, int WC, int EPI>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p,
@@ -127,14 +147,8 @@ __global__ __launch_bounds__(WR* WC * 64) void gemm_nt_kernel(const GemmParams p
   using Cfg = GemmCfg<BM, BN, WR, WC>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-  // ---- XCD-aware tile order: ids that share an XCD (id % 8) get a contiguous run ----
-  const int nwg = p.tiles_m * p.tiles_n;
-  const int orig = blockIdx.x;
-  const int xcd = orig & 7;
-  const int q = nwg >> 3, r8 = nwg & 7;
-  const int wgid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (orig >> 3);
-  const int tn = wgid / p.tiles_m;  // M fastest inside an N panel
-  const int tm = wgid - tn * p.tiles_m;
+  int tm, tn;
+  gemm_tile_coords(p, tm, tn);
   const int64_t m0 = (int64_t)tm * BM;
   const int64_t n0 = (int64_t)tn * BN;
 
@@ -254,156 +268,6 @@ __global__ __launch_bounds__(WR* WC * 64) void gemm_nt_kernel(const GemmParams p
   gemm_epilogue<BM, BN, WR, WC, EPI>(p, acc, m0, n0, wr, wc, r, h);
 }
 
-// ---------------------------------------------------------------------------
-// Deep-prefetch variant for the large token-side projections: BK = 32, a 4-slot LDS ring (4 x 32 KiB at 256x256),
-// LDS-DMA for three K-steps kept in flight across RAW s_barriers behind a COUNTED s_waitcnt vmcnt(N) (a
-// __syncthreads() would drain the DMA queue: cdna_hip_programming.md, "Pipelining across barriers").  One K-step
-// of look-ahead (the 2-buffer kernel above) is shorter than the loaded-chip LDS-DMA latency, this ring is not.
-//   LDS image per operand: rows of 64 B, 16 rows per 1-KiB wave-instruction; 16-byte slot s of row r is stored at
-//   slot s ^ ((r >> 2) & 3), which makes the ds_read_b128 fragment reads (16 distinct rows per lane group)
-//   conflict-free: a 256-B bank row holds 4 rows x 4 slots and (r & 3, s ^ (r>>2)&3) is distinct over 16 rows.
-// ---------------------------------------------------------------------------
-template <int BM, int BN, int WR, int WC, int EPI>
-__global__ __launch_bounds__(WR* WC * 64) void gemm_nt_p4_kernel(const GemmParams p) {
-  using Cfg = GemmCfg<BM, BN, WR, WC>;
-  constexpr int NSTAGE = 4;
-  constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64, STAGE = A_BYTES + B_BYTES;
-  constexpr int IA = BM / 16 / Cfg::NW, IB = BN / 16 / Cfg::NW;  // LDS-DMA wave-instructions per wave and K-step
-  constexpr int LPS = IA + IB;                                    // loads per stage per wave
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-  const int nwg = p.tiles_m * p.tiles_n;
-  const int orig = blockIdx.x;
-  const int xcd = orig & 7;
-  const int q = nwg >> 3, r8 = nwg & 7;
-  const int wgid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (orig >> 3);
-  const int tn = wgid / p.tiles_m;
-  const int tm = wgid - tn * p.tiles_m;
-  const int64_t m0 = (int64_t)tm * BM;
-  const int64_t n0 = (int64_t)tn * BN;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave / WC, wc = wave % WC;
-  const int r = lane & 31, h = lane >> 5;
-
-  // per-lane source pointers (row clamped at the tails), swizzle folded in; the LoRA operand pair has its own
-  const int ld_row = lane >> 2, ld_slot = lane & 3;
-  const bf16_t* a_ptr[IA];
-  const bf16_t* b_ptr[IB];
-  const bf16_t* a2_ptr[IA];
-  const bf16_t* b2_ptr[IB];
-#pragma unroll
-  for (int t = 0; t < IA; ++t) {
-    const int row = (wave * IA + t) * 16 + ld_row;
-    int64_t g = m0 + row;
-    if (g > p.M - 1) g = p.M - 1;
-    const int sw = (ld_slot ^ ((row >> 2) & 3)) * 8;
-    a_ptr[t] = p.a + g * p.lda + sw;
-    a2_ptr[t] = p.a2 ? p.a2 + g * p.lda2 + sw : nullptr;
-  }
-#pragma unroll
-  for (int t = 0; t < IB; ++t) {
-    const int row = (wave * IB + t) * 16 + ld_row;
-    int64_t g = n0 + row;
-    if (g > p.N - 1) g = p.N - 1;
-    const int sw = (ld_slot ^ ((row >> 2) & 3)) * 8;
-    b_ptr[t] = p.w + g * p.ldw + sw;
-    b2_ptr[t] = p.w2 ? p.w2 + g * p.ldw2 + sw : nullptr;
-  }
-  const int nk1 = p.nk1 * 2, nk = (p.nk1 + p.nk2) * 2;  // 32-deep K-steps
-
-  auto stage = [&](int kt) {
-    unsigned char* sa = smem + (kt & (NSTAGE - 1)) * STAGE;
-    unsigned char* sb = sa + A_BYTES;
-    if (kt < nk1) {
-      const int k0 = kt * 32;
-#pragma unroll
-      for (int t = 0; t < IA; ++t)
-        __builtin_amdgcn_global_load_lds((gbl_void*)(a_ptr[t] + k0), (lds_void*)(sa + (wave * IA + t) * 1024), 16, 0, 0);
-#pragma unroll
-      for (int t = 0; t < IB; ++t)
-        __builtin_amdgcn_global_load_lds((gbl_void*)(b_ptr[t] + k0), (lds_void*)(sb + (wave * IB + t) * 1024), 16, 0, 0);
-    } else {
-      const int k0 = (kt - nk1) * 32;
-#pragma unroll
-      for (int t = 0; t < IA; ++t)
-        __builtin_amdgcn_global_load_lds((gbl_void*)(a2_ptr[t] + k0), (lds_void*)(sa + (wave * IA + t) * 1024), 16, 0, 0);
-#pragma unroll
-      for (int t = 0; t < IB; ++t)
-        __builtin_amdgcn_global_load_lds((gbl_void*)(b2_ptr[t] + k0), (lds_void*)(sb + (wave * IB + t) * 1024), 16, 0, 0);
-    }
-  };
-
-  f32x16 acc[Cfg::TM][Cfg::TN];
-#pragma unroll
-  for (int i = 0; i < Cfg::TM; ++i)
-#pragma unroll
-    for (int j = 0; j < Cfg::TN; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  const int sw = (r >> 2) & 3;
-  const int a_off = (wr * (BM / WR) + r) * 64;
-  const int b_off = (wc * (BN / WC) + r) * 64;
-
-  // prologue: three K-steps in flight
-  stage(0);
-  if (nk > 1) stage(1);
-  if (nk > 2) stage(2);
-  for (int kt = 0; kt < nk; ++kt) {
-    // K-step kt must have landed; the (up to) two younger ones stay in flight across the barrier
-    const int younger = nk - 1 - kt;
-    if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
-    else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // all waves' pieces of K-step kt landed; slot (kt+3)&3 is no longer being read
-    if (kt + 3 < nk) stage(kt + 3);
-    const unsigned char* sa = smem + (kt & (NSTAGE - 1)) * STAGE;
-    const unsigned char* sb = sa + A_BYTES;
-    bf16x8 af[2][Cfg::TM], bfr[2][Cfg::TN];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int ch = ((2 * ks + h) ^ sw) * 16;
-#pragma unroll
-      for (int i = 0; i < Cfg::TM; ++i) af[ks][i] = *reinterpret_cast<const bf16x8*>(sa + a_off + i * 32 * 64 + ch);
-#pragma unroll
-      for (int j = 0; j < Cfg::TN; ++j) bfr[ks][j] = *reinterpret_cast<const bf16x8*>(sb + b_off + j * 32 * 64 + ch);
-    }
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int i = 0; i < Cfg::TM; ++i)
-#pragma unroll
-        for (int j = 0; j < Cfg::TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-  }
-  gemm_epilogue<BM, BN, WR, WC, EPI>(p, acc, m0, n0, wr, wc, r, h);
-}
-
-template <int BM, int BN, int WR, int WC, int EPI>
-static int launch_gemm_p4(GemmParams& p, hipStream_t s) {
-  using Cfg = GemmCfg<BM, BN, WR, WC>;
-  p.tiles_m = (int)((p.M + BM - 1) / BM);
-  p.tiles_n = (int)((p.N + BN - 1) / BN);
-  const size_t lds = 4 * (size_t)(BM + BN) * 64;
-  auto kern = gemm_nt_p4_kernel<BM, BN, WR, WC, EPI>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-      lcv_set_error("gemm_nt: cannot raise dynamic LDS to %zu", lds);
-      return LCV_EDEVICE;
-    }
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(kern, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(Cfg::NT), lds, s, p);
-  LCV_LAUNCH_CHECK("gemm_nt_p4");
-  return LCV_OK;
-}
-
 template <int BM, int BN, int WR, int WC, int EPI, bool CONV>
 static int launch_gemm(GemmParams& p, hipStream_t s) {
   using Cfg = GemmCfg<BM, BN, WR, WC>;
@@ -426,13 +290,10 @@ static int launch_gemm(GemmParams& p, hipStream_t s) {
 
 template <int EPI>
 static int dispatch_tile(GemmParams& p, hipStream_t s) {
-  // big token-side projections: 256x256 tiles, two LDS buffers (measured 982-1030 TF/s at K3 shapes; the 4-slot
-  // BK=32 ring measured 932-953: its extra barrier per 16 MFMAs costs more than the deeper prefetch returns);
-  // small M or N: 128x128.  LCV_GEMM_TILE = 1 | 2 | 4 forces 128x128 / 256x256 two-buffer / 256x256 ring.
+  // big token-side projections: 256x256 tiles; small M or N: 128x128.  LCV_GEMM_TILE = 1 | 2 forces a tile (tests).
   const char* force = getenv("LCV_GEMM_TILE");
   int mode = (p.M >= 2048 && p.N >= 1024) ? 2 : 1;
   if (force) mode = force[0] - '0';
-  if (mode == 4) return launch_gemm_p4<256, 256, 2, 4, EPI>(p, s);
   if (mode == 2) return launch_gemm<256, 256, 2, 4, EPI, false>(p, s);
   return launch_gemm<128, 128, 2, 2, EPI, false>(p, s);
 }

@@ -119,7 +119,7 @@ def test_attention_strided_packed_qkv_and_spike():
     assert rel_l2(o.permute(0, 2, 1, 3), ref) < 6e-3
 
 
-@pytest.mark.parametrize("M,N,K,tile", [(300, 192, 128, "1"), (70, 64, 64, "1"), (2050, 1024, 256, "2"), (513, 768, 192, "2"), (2050, 1024, 256, "4"), (513, 768, 64, "4"), (700, 300, 1088, "4")])
+@pytest.mark.parametrize("M,N,K,tile", [(300, 192, 128, "1"), (70, 64, 64, "1"), (2050, 1024, 256, "2"), (513, 768, 192, "2"), (700, 300, 1088, "2")])
 def test_gemm_nt_bias(M, N, K, tile, monkeypatch):
     monkeypatch.setenv("LCV_GEMM_TILE", tile)
     ops, orc = _ops(), _orc()
