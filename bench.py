@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--guidance-scale", type=float, default=4.0)
     ap.add_argument("--depth", type=int, default=48, help="debug only: anything but 48 is not the named model")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the untimed extras (VAE decode and LoRA-TTA inner-loop step times for the per-video wall clock)")
     ap.add_argument("--parallelism", default="dp", choices=["dp", "sp"],
                     help="dp: one independent video per GPU (weak scaling, default); sp: ONE video, latent frames sharded "
                          "over the GPUs with an RCCL K/V all-gather per attention layer (strong scaling, config K5)")
@@ -91,6 +93,44 @@ def cpu_baseline(num_inference_steps: int) -> dict:
             "sample": f"K1 {WORKLOADS['K1'][3]}: 2 of 48 blocks at full width timed (best of {max(len(times) - 1, 1)} after warm-up, "
                       f"{per_block:.2f} s/block), linear extrapolation to 48 blocks x 2 CFG forwards; fp32 math at "
                       "the bf16 rounding points"}
+
+
+def measure_extras(dit, dev, T, h, w, pe, pm) -> dict:
+    """VAE decode of the finished clip and the LoRA-TTA inner-loop step (lora_experiment config: r=8, alpha 16,
+    qkv+proj on all 48 blocks, Tc=4 clean + Tt=3 noised latent frames at the bench resolution)."""
+    import gc
+    from longcat_video.modules.autoencoder_kl_wan import AutoencoderKLWan
+    from tta.inner_loop import choose_gradient_checkpointing, finetune_lora_on_conditioning
+    from tta.lora import inject_lora_into_dit, remove_lora_from_dit
+    out = {}
+    vae = AutoencoderKLWan(device=dev).init_synthetic_()
+    z = torch.randn((1, 16, T, h, w), device=dev).to(torch.bfloat16)
+    vae.decode(z)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    vae.decode(z)
+    torch.cuda.synchronize(); out["vae_decode_s"] = time.perf_counter() - t0
+    del vae, z
+    for b in dit.blocks:          # the fused SwiGLU weight copies are inference-only: give their 9 GB to the activations
+        b.ffn._w13 = None
+    gc.collect(); torch.cuda.empty_cache()
+    for p in dit.parameters():
+        p.requires_grad = False
+    mods = inject_lora_into_dit(dit, rank=8, alpha=16.0, target_modules=["qkv", "proj"])
+    g = torch.Generator(device=dev).manual_seed(7)
+    cond = torch.randn((1, 16, 4, h, w), generator=g, device=dev).to(torch.bfloat16)
+    train = torch.randn((1, 16, 3, h, w), generator=g, device=dev).to(torch.bfloat16)
+    ckpt = choose_gradient_checkpointing(dit, 7 * (h // 2) * (w // 2))
+    kw = dict(lr=2e-4, warmup_steps=3, device=str(dev), dtype=torch.bfloat16)
+    finetune_lora_on_conditioning(dit, mods, cond, train, pe, pm, num_steps=1, **kw)   # warm-up: builds the W^T copies
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    res = finetune_lora_on_conditioning(dit, mods, cond, train, pe, pm, num_steps=2, **kw)
+    torch.cuda.synchronize()
+    out["tta_step_s"] = (time.perf_counter() - t0) / 2
+    out["tta_tokens"] = 7 * (h // 2) * (w // 2)
+    out["tta_block_checkpointing"] = bool(ckpt)
+    out["tta_losses"] = [round(x, 4) for x in res["losses"]]
+    remove_lora_from_dit(dit)
+    return out
 
 
 def main():
@@ -167,6 +207,13 @@ def main():
     assert torch.isfinite(x).all().item(), "non-finite latents"
 
     sec_per_step = elapsed / args.steps
+
+    # ---- extras (outside the timed region, rank 0 of a 1-GPU run): the other two legs of "wall-clock per TTA video" ----
+    extras = {}
+    if world == 1 and not args.no_extras and args.depth == 48:
+        extras = measure_extras(dit, dev, T, h, w, pe, pm)
+        extras["wall_clock_per_tta_video_s_extrapolated"] = (
+            20 * extras["tta_step_s"] + args.num_inference_steps * sec_per_step + extras["vae_decode_s"])
     per_gpu = T / (args.num_inference_steps * sec_per_step)
     value = per_gpu if sp else per_gpu * world
 
@@ -192,7 +239,7 @@ def main():
                                f"{args.num_inference_steps}-step flow-match Euler, no conditioning frames",
                    "depth": args.depth, "tokens": T * (h // 2) * (w // 2), "parallelism": f"{'sp' if sp else 'dp'}{world}",
                    "latent_frame_steps_per_s": T * (1 if sp else world) / sec_per_step,
-                   "wall_clock_per_video_s_extrapolated": sec_per_step * args.num_inference_steps},
+                   "wall_clock_per_video_s_extrapolated": sec_per_step * args.num_inference_steps, **extras},
         "roofline": {"kernel": "attn_fwd_kernel<8, 0, false>", "bound": "mfma", "achieved": achieved, "peak": MFMA_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": traffic,
                      "avg_launch_ms": avg_ms, "launches": len(big), "flops_per_launch": flops},

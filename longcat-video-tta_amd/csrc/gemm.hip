@@ -82,7 +82,12 @@ __device__ __forceinline__ void gemm_tile_coords(const GemmParams& p, int& tm, i
   tn = in_group / gsz;
 }
 
-// ---- shared epilogue: acc[i][j][e] is C[row = (e&3)+8*(e>>2)+4*h][col = lane&31] of its 32x32 tile ----
+// ---- shared epilogue ----
+// The MFMAs are issued with the WEIGHT fragment as the A operand and the ACTIVATION fragment as the B operand, so the
+// accumulator holds C^T: acc[i][j][e] = C[m = mw + 32 i + (lane & 31)][n = nw + 32 j + (e&3) + 8 (e>>2) + 4 (lane>>5)].
+// A lane therefore owns ONE output row per i and 4 CONSECUTIVE columns per register group: the store is 8 bytes
+// (bf16) or 16 bytes (fp32) per lane and instruction instead of 2 — a quarter of the store instructions, and bias /
+// residual / gate come in as 8- and 16-byte loads.
 template <int BM, int BN, int WR, int WC, int EPI>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p,
                                               f32x16 (&acc)[GemmCfg<BM, BN, WR, WC>::TM][GemmCfg<BM, BN, WR, WC>::TN],
@@ -90,55 +95,101 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p,
   using Cfg = GemmCfg<BM, BN, WR, WC>;
   const int64_t mw = m0 + wr * (BM / WR);
   const int64_t nw = n0 + wc * (BN / WC);
-  if constexpr (EPI == LCV_EPI_SWIGLU) {
-    // W rows interleaved [32 gate | 32 up]: tile j even = gate, j odd = up of the same 32 features
-    bf16_t* C = (bf16_t*)p.c;
+  const bool vec = (p.ldc % 4 == 0) && (((uintptr_t)p.c & 15) == 0);  // 4-column groups are naturally aligned
 #pragma unroll
-    for (int i = 0; i < Cfg::TM; ++i)
+  for (int i = 0; i < Cfg::TM; ++i) {
+    const int64_t m = mw + i * 32 + r;
+    if (m >= p.M) continue;
+    const float* grow = nullptr;
+    if constexpr (EPI == LCV_EPI_GATE_RESIDUAL) {
+      if (p.gate) grow = p.gate + (m / p.rows_per_frame) * p.mod_stride;
+    }
+    if constexpr (EPI == LCV_EPI_SWIGLU) {
+      // W rows interleaved [32 gate | 32 up]: tile j even = gate, j odd = up of the same 32 features
+      bf16_t* C = (bf16_t*)p.c + m * p.ldc;
 #pragma unroll
-      for (int jj = 0; jj < Cfg::TN / 2; ++jj) {
-        const int64_t ng = nw + jj * 64 + r;  // gate column in the interleaved weight
-        if (ng >= p.N) continue;
-        const float bg = p.bias ? bf2f(p.bias[ng]) : 0.f;
-        const float bu = p.bias ? bf2f(p.bias[ng + 32]) : 0.f;
-        const int64_t f = (nw + jj * 64) / 2 + r;
+      for (int jj = 0; jj < Cfg::TN / 2; ++jj)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int64_t m = mw + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-          if (m < p.M) {
-            const float g = bfround(acc[i][2 * jj][e] + bg);
-            const float u = bfround(acc[i][2 * jj + 1][e] + bu);
-            C[m * p.ldc + f] = f2bf(bfround(silu_f(g)) * u);
+        for (int g = 0; g < 4; ++g) {
+          const int64_t ng = nw + jj * 64 + 8 * g + 4 * h;  // gate column in the interleaved weight
+          if (ng >= p.N) continue;
+          const int64_t f = (nw + jj * 64) / 2 + 8 * g + 4 * h;
+          u16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float bg = p.bias ? bf2f(p.bias[ng + e]) : 0.f;
+            const float bu = p.bias ? bf2f(p.bias[ng + 32 + e]) : 0.f;
+            const float gv = bfround(acc[i][2 * jj][4 * g + e] + bg);
+            const float uv = bfround(acc[i][2 * jj + 1][4 * g + e] + bu);
+            o[e] = f2bf(bfround(silu_f(gv)) * uv);
+          }
+          if (vec) *reinterpret_cast<u16x4*>(C + f) = o;
+          else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) C[f + e] = o[e];
           }
         }
-      }
-  } else {
+    } else {
 #pragma unroll
-    for (int i = 0; i < Cfg::TM; ++i)
+      for (int j = 0; j < Cfg::TN; ++j)
 #pragma unroll
-      for (int j = 0; j < Cfg::TN; ++j) {
-        const int64_t n = nw + j * 32 + r;
-        if (n >= p.N) continue;
-        const float b = p.bias ? bf2f(p.bias[n]) : 0.f;
+        for (int g = 0; g < 4; ++g) {
+          const int64_t n = nw + j * 32 + 8 * g + 4 * h;
+          if (n >= p.N) continue;
+          const bool full = vec && (n + 3 < p.N);
+          float v[4];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int64_t m = mw + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-          if (m < p.M) {
-            float v = acc[i][j][e] + b;
-            if constexpr (EPI == LCV_EPI_GATE_RESIDUAL) {
-              const float xs = bfround(v);  // the projection output is a bf16 tensor upstream
-              const float g = p.gate ? p.gate[(m / p.rows_per_frame) * p.mod_stride + n] : 1.0f;
-              v = bf2f(p.resid[m * p.ldc + n]) + g * xs;
-            } else if constexpr (EPI == LCV_EPI_GELU_TANH) {
-              v = gelu_tanh_f(bfround(v));
-            } else if constexpr (EPI == LCV_EPI_SILU) {
-              v = silu_f(bfround(v));
+          for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
+          if (p.bias) {
+            if (full) {
+              const u16x4 b4 = *reinterpret_cast<const u16x4*>(p.bias + n);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] += bf2f(b4[e]);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (n + e < p.N) v[e] += bf2f(p.bias[n + e]);
             }
-            if (p.out_f32) ((float*)p.c)[m * p.ldc + n] = v;
-            else ((bf16_t*)p.c)[m * p.ldc + n] = f2bf(v);
+          }
+          if constexpr (EPI == LCV_EPI_GATE_RESIDUAL) {
+            // the projection output is a bf16 tensor upstream: round, then resid + gate * xs in fp32
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              if (n + e < p.N) {
+                const float gt = grow ? grow[n + e] : 1.0f;
+                v[e] = bf2f(p.resid[m * p.ldc + n + e]) + gt * bfround(v[e]);
+              }
+            }
+          } else if constexpr (EPI == LCV_EPI_GELU_TANH) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(bfround(v[e]));
+          } else if constexpr (EPI == LCV_EPI_SILU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = silu_f(bfround(v[e]));
+          }
+          if (p.out_f32) {
+            float* C = (float*)p.c + m * p.ldc + n;
+            if (full) *reinterpret_cast<f32x4*>(C) = f32x4{v[0], v[1], v[2], v[3]};
+            else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (n + e < p.N) C[e] = v[e];
+            }
+          } else {
+            bf16_t* C = (bf16_t*)p.c + m * p.ldc + n;
+            if (full) {
+              u16x4 o;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
+              *reinterpret_cast<u16x4*>(C) = o;
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (n + e < p.N) C[e] = f2bf(v[e]);
+            }
           }
         }
-      }
+    }
   }
 }
 
@@ -261,7 +312,7 @@ __global__ __launch_bounds__(WR* WC * 64) void gemm_nt_kernel(const GemmParams p
       for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
         for (int j = 0; j < Cfg::TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);  // C^T tile
     }
   }
 

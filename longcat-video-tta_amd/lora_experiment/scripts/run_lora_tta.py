@@ -35,7 +35,7 @@ import torch  # noqa: E402
 from longcat_video.parallel import data_parallel as dp  # noqa: E402
 from tta import cli_args as C  # noqa: E402
 from tta.early_stopping import add_early_stopping_args, build_early_stopper_from_args  # noqa: E402
-from tta.inner_loop import finetune_lora_on_conditioning  # noqa: E402
+from tta.inner_loop import choose_gradient_checkpointing, finetune_lora_on_conditioning  # noqa: E402
 from tta.latent_split import _estimate_latent_len, num_frames_valid, split_tta_latents  # noqa: E402
 from tta.lora import (count_lora_parameters, get_lora_parameters, inject_lora_into_dit, reset_lora_weights,  # noqa: E402
                       save_lora_weights)
@@ -177,9 +177,8 @@ def main(argv=None):
     done = {r["idx"] for r in all_results}
 
     dit, pipe = load_components(args, device)
-    from torch.utils.checkpoint import checkpoint
-    dit.gradient_checkpointing = True                      # run_lora_tta.py:806-811
-    dit._gradient_checkpointing_func = functools.partial(checkpoint, use_reentrant=False)
+    # run_lora_tta.py:806-811 switches block checkpointing on unconditionally; here it is decided per video from the
+    # token count (LCV_TTA_CHECKPOINT=on reproduces the reference): see tta.inner_loop.choose_gradient_checkpointing
     for p in dit.parameters():                             # :813-815
         p.requires_grad = False
     target_modules = [m.strip() for m in args.target_modules.split(",") if m.strip()]
@@ -223,6 +222,8 @@ def main(argv=None):
             torch.manual_seed(dp.seed_for_video(args.seed, idx))
             blob = load_entry(e, args, dit, device)
             cond, train, val = split_tta_latents(blob["latents"], n_ctx_lat, args.es_holdout_fraction)
+            n_tok = (cond.shape[2] + train.shape[2]) * (cond.shape[3] // 2) * (cond.shape[4] // 2)
+            choose_gradient_checkpointing(dit, n_tok)
             reset_lora_weights(lora_modules)
             es = early_stopper if (early_stopper is not None and val is not None) else None
             if es is not None:
