@@ -119,7 +119,7 @@ def test_attention_strided_packed_qkv_and_spike():
     assert rel_l2(o.permute(0, 2, 1, 3), ref) < 6e-3
 
 
-@pytest.mark.parametrize("M,N,K,tile", [(300, 192, 128, "1"), (70, 64, 64, "1"), (2050, 1024, 256, "2"), (513, 768, 192, "2"), (700, 300, 1088, "2")])
+@pytest.mark.parametrize("M,N,K,tile", [(300, 192, 128, "1"), (70, 64, 64, "1"), (2050, 1024, 256, "2"), (513, 768, 192, "2"), (700, 300, 1088, "2"), (2050, 1024, 256, "6"), (513, 768, 192, "6"), (700, 300, 1088, "6"), (300, 192, 128, "7"), (70, 64, 64, "7")])
 def test_gemm_nt_bias(M, N, K, tile, monkeypatch):
     monkeypatch.setenv("LCV_GEMM_TILE", tile)
     ops, orc = _ops(), _orc()
@@ -131,7 +131,9 @@ def test_gemm_nt_bias(M, N, K, tile, monkeypatch):
     assert rel_l2(c32, orc.linear(a, w, b)) < 1e-5
 
 
-def test_gemm_nt_lora_and_epilogues():
+@pytest.mark.parametrize("tile", ["1", "7"])
+def test_gemm_nt_lora_and_epilogues(tile, monkeypatch):
+    monkeypatch.setenv("LCV_GEMM_TILE", tile)
     ops, orc = _ops(), _orc()
     from lcv_hip.lib import LCV_EPI_GATE_RESIDUAL, LCV_EPI_GELU_TANH, LCV_EPI_SWIGLU
     import torch.nn.functional as F
