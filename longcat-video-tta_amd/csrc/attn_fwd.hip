@@ -16,6 +16,7 @@
 //     one XOR-swizzled 256-byte-row image that is conflict-free for both read kinds.
 //   * algorithmic work per launch: 4*Nq*Nk*128 flop and (Nq*2 + Nk*2)*128*2 bytes per (b, h).
 #include "lcv_common.h"
+#include <type_traits>
 
 typedef __attribute__((address_space(3))) unsigned char lds_u8;
 
@@ -64,8 +65,18 @@ __device__ __forceinline__ int tile_off(int row, int ch) {
 
 // XATTN only names the instantiation used for the short-KV text cross-attention (Nk <= 512) so that profiles list it
 // separately from the self-attention launches (the dominant kernel); the code path is the same.
-template <int NWAVES, int PRIO, bool XATTN>
+//
+// VAR bit 0: K/V tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4; the swizzle is applied on the SOURCE column,
+//            the destination is lane-linear) from per-lane pointers that advance by one tile per iteration: no staging
+//            registers, no ds_write, no per-tile 64-bit address arithmetic.
+//            (+3.6 % at N = 46 800.  Tried and dropped: row sums on the matrix core with an all-ones A operand, -3.6 %.)
+typedef __attribute__((address_space(1))) void gbl_void_t;
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+template <int NWAVES, int PRIO, bool XATTN, int VAR>
 __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnFwdParams p) {
+  constexpr bool DMA = (VAR & 1) != 0;
+  static_assert(!DMA || NWAVES == 8, "LDS-DMA staging is laid out for 8 waves (2 K + 2 V instructions per wave)");
   constexpr int NT = NWAVES * 64;
   constexpr int QROWS = NWAVES * 32;
   constexpr int NCH = 1024 / NT;  // 16-byte chunks per thread per 64x128 tile
@@ -118,6 +129,39 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnFwdPara
   }
   const int st_col = (tid & 15) * 8;
   u32x4 kreg[NCH], vreg[NCH];
+  // LDS-DMA roles: wave w fills rows 8 w .. 8 w + 7 of both tiles with 2 + 2 one-KiB instructions; lane l of instruction i
+  // lands at row 8 w + 4 i + (l >> 4), physical chunk l & 15, which holds logical chunk (l & 15) ^ swizzle(row)
+  const bf16_t* kdma[2];
+  const bf16_t* vdma[2];
+  int dma_row[2], dma_col[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    dma_row[i] = 8 * wave + 4 * i + (lane >> 4);
+    dma_col[i] = 8 * ((lane & 15) ^ (((dma_row[i] & 3) << 2) | ((dma_row[i] >> 2) & 3)));
+    kdma[i] = kbase + dma_row[i] * p.k_sn + dma_col[i];
+    vdma[i] = vbase + dma_row[i] * p.v_sn + dma_col[i];
+  }
+  const int64_t kstep = 64 * p.k_sn, vstep = 64 * p.v_sn;
+  auto dma_tile = [&](int t, int buf) {  // issue tile t into buffer buf; kdma/vdma point at this lane's rows of tile t
+    lds_u8* kb = lds + buf * 2 * TILE_BYTES + wave * 2048;
+    if ((int64_t)t * 64 + 64 <= p.Nk) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)kdma[i], (lds_void_t*)(kb + 1024 * i), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)vdma[i], (lds_void_t*)(kb + TILE_BYTES + 1024 * i), 16, 0, 0);
+        kdma[i] += kstep;
+        vdma[i] += vstep;
+      }
+    } else {  // ragged last tile: rows past Nk re-read the last key (masked below)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        int64_t back = (int64_t)t * 64 + dma_row[i] - (p.Nk - 1);
+        if (back < 0) back = 0;
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(kdma[i] - back * p.k_sn), (lds_void_t*)(kb + 1024 * i), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(vdma[i] - back * p.v_sn), (lds_void_t*)(kb + TILE_BYTES + 1024 * i), 16, 0, 0);
+      }
+    }
+  };
   auto load_tile = [&](int64_t kv0) {
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
@@ -158,14 +202,21 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnFwdPara
 
   if (PRIO == 1 && wave >= NWAVES / 2) __builtin_amdgcn_s_setprio(1);  // static priority for the younger half
   const int nt = (int)((p.Nk + 63) / 64);
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
+  if (DMA) {
+    dma_tile(0, 0);
+  } else {
+    load_tile(0);
+    store_tile(0);
+  }
+  __syncthreads();  // (drains this wave's LDS-DMA: vmcnt 0)
 
-  for (int t = 0; t < nt; ++t) {
-    const int buf = t & 1;
+  auto tile_body = [&](const int t, auto buf_c) {
+    constexpr int buf = decltype(buf_c)::value;  // compile-time buffer: every LDS address is a fixed register + immediate
     const bool has_next = (t + 1 < nt);
-    if (has_next) load_tile((int64_t)(t + 1) * 64);
+    if (has_next) {
+      if (DMA) dma_tile(t + 1, buf ^ 1);  // buf ^ 1 was last read in iteration t-1; every wave has passed its barrier
+      else load_tile((int64_t)(t + 1) * 64);
+    }
 
     const lds_u8* kb = lds + buf * 2 * TILE_BYTES;
     const lds_u8* vb = kb + TILE_BYTES;
@@ -174,7 +225,6 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnFwdPara
     f32x16 s0, s1;
 #pragma unroll
     for (int e = 0; e < 16; ++e) { s0[e] = 0.f; s1[e] = 0.f; }
-    if (PRIO == 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
       const int co = 16 * ((2 * ks + h) ^ kf);
@@ -183,7 +233,6 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnFwdPara
       s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qf[ks], s0, 0, 0, 0);
       s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qf[ks], s1, 0, 0, 0);
     }
-    if (PRIO == 2) __builtin_amdgcn_s_setprio(0);
 
     // ---- mask keys past Nk (last tile only; wave-uniform branch) ----
     if (!has_next && (p.Nk & 63)) {
@@ -241,7 +290,6 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnFwdPara
     }
 
     // ---- O^T += V^T P^T ----
-    if (PRIO == 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
@@ -258,9 +306,12 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnFwdPara
       }
     }
 
-    if (PRIO == 2) __builtin_amdgcn_s_setprio(0);
-    if (has_next) store_tile(buf ^ 1);
+    if (has_next && !DMA) store_tile(buf ^ 1);
     __syncthreads();
+  };
+  for (int t = 0; t < nt; t += 2) {
+    tile_body(t, std::integral_constant<int, 0>{});
+    if (t + 1 < nt) tile_body(t + 1, std::integral_constant<int, 1>{});
   }
 
   // ---- epilogue ----
@@ -305,7 +356,7 @@ extern "C" int lcv_attn_fwd(const void* q, const void* k, const void* v, void* o
   p.scale = scale; p.scale_log2e = scale * 1.4426950408889634f;
   constexpr int NW = 8;
   const size_t lds = 2 * 2 * 64 * 256;
-  const char* pe = getenv("LCV_ATTN_PRIO");  // 0 none, 1 static priority for waves 4-7, 2 per MFMA cluster (A/B knob)
+  const char* pe = getenv("LCV_ATTN_PRIO");  // 0 none, 1 static priority for waves 4-7 (A/B knob)
   const int prio = pe ? pe[0] - '0' : 0;
   const unsigned gx = (unsigned)((Nq + NW * 32 - 1) / (NW * 32));
   const char* xe = getenv("LCV_ATTN_XCD");  // A/B knob: 0 disables the head-per-XCD block order
@@ -320,11 +371,13 @@ extern "C" int lcv_attn_fwd(const void* q, const void* k, const void* v, void* o
     hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, (hipStream_t)stream, p);
     return LCV_OK;
   };
+  const char* ve = getenv("LCV_ATTN_VAR");  // A/B knob: 0 = register-staged K/V tiles instead of LDS-DMA
+  const int var = ve ? (ve[0] - '0') & 1 : 1;
   int rc;
-  if (Nk <= 512) rc = launch(attn_fwd_kernel<NW, 0, true>);
-  else if (prio == 1) rc = launch(attn_fwd_kernel<NW, 1, false>);
-  else if (prio == 2) rc = launch(attn_fwd_kernel<NW, 2, false>);
-  else rc = launch(attn_fwd_kernel<NW, 0, false>);
+  if (Nk <= 512) rc = launch(attn_fwd_kernel<NW, 0, true, 0>);
+  else if (prio == 1) rc = launch(attn_fwd_kernel<NW, 1, false, 0>);
+  else if (var == 0) rc = launch(attn_fwd_kernel<NW, 0, false, 0>);
+  else rc = launch(attn_fwd_kernel<NW, 0, false, 1>);
   if (rc != LCV_OK) return rc;
   LCV_LAUNCH_CHECK("attn_fwd");
   return LCV_OK;

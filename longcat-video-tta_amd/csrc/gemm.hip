@@ -15,6 +15,7 @@
 //   * XCD-aware block order: consecutive workgroup ids on one XCD walk down M inside one
 //     N panel, so the W panel stays in that XCD's L2.
 #include "lcv_common.h"
+#include <type_traits>
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_void;
@@ -331,6 +332,102 @@ __global__ __launch_bounds__(WR* WC * 64) void gemm_nt_kernel(const GemmParams p
 // ---------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(4))) float f32x4v;
 
+// ---- epilogue of the 16x16x32 kernels: acc[i][j][e] = C[m = mw + 16 i + (lane & 15)][n = nw + 16 j + 4 (lane >> 4) + e] ----
+template <int TM, int TN, int EPI>
+__device__ __forceinline__ void gemm16_epilogue(const GemmParams& p, f32x4v (&acc)[TM][TN], int64_t mw, int64_t nw, int r16,
+                                                int q) {
+  // ---- epilogue: lane owns row m and 4 consecutive columns per (i, j) ----
+  const bool vec = (p.ldc % 4 == 0) && (((uintptr_t)p.c & 15) == 0);
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int64_t m = mw + i * 16 + r16;
+    if (m >= p.M) continue;
+    const float* grow = nullptr;
+    if constexpr (EPI == LCV_EPI_GATE_RESIDUAL) {
+      if (p.gate) grow = p.gate + (m / p.rows_per_frame) * p.mod_stride;
+    }
+    if constexpr (EPI == LCV_EPI_SWIGLU) {
+      // W rows interleaved [32 gate | 32 up]: within a 64-row block, 16-wide tiles 0,1 are gate and 2,3 their up partners
+      bf16_t* C = (bf16_t*)p.c + m * p.ldc;
+#pragma unroll
+      for (int jb = 0; jb < TN / 4; ++jb)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int64_t ng = nw + jb * 64 + 16 * u + 4 * q;
+          if (ng >= p.N) continue;
+          const int64_t f = (nw + jb * 64) / 2 + 16 * u + 4 * q;
+          u16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float bg = p.bias ? bf2f(p.bias[ng + e]) : 0.f;
+            const float bu = p.bias ? bf2f(p.bias[ng + 32 + e]) : 0.f;
+            const float gv = bfround(acc[i][4 * jb + u][e] + bg);
+            const float uv = bfround(acc[i][4 * jb + 2 + u][e] + bu);
+            o[e] = f2bf(bfround(silu_f(gv)) * uv);
+          }
+          if (vec) *reinterpret_cast<u16x4*>(C + f) = o;
+          else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) C[f + e] = o[e];
+          }
+        }
+    } else {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int64_t n = nw + j * 16 + 4 * q;
+        if (n >= p.N) continue;
+        const bool full = vec && (n + 3 < p.N);
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e];
+        if (p.bias) {
+          if (full) {
+            const u16x4 b4 = *reinterpret_cast<const u16x4*>(p.bias + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += bf2f(b4[e]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (n + e < p.N) v[e] += bf2f(p.bias[n + e]);
+          }
+        }
+        if constexpr (EPI == LCV_EPI_GATE_RESIDUAL) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (n + e < p.N) v[e] = bf2f(p.resid[m * p.ldc + n + e]) + (grow ? grow[n + e] : 1.0f) * bfround(v[e]);
+        } else if constexpr (EPI == LCV_EPI_GELU_TANH) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(bfround(v[e]));
+        } else if constexpr (EPI == LCV_EPI_SILU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = silu_f(bfround(v[e]));
+        }
+        if (p.out_f32) {
+          float* C = (float*)p.c + m * p.ldc + n;
+          if (full) *reinterpret_cast<f32x4*>(C) = f32x4{v[0], v[1], v[2], v[3]};
+          else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (n + e < p.N) C[e] = v[e];
+          }
+        } else {
+          bf16_t* C = (bf16_t*)p.c + m * p.ldc + n;
+          if (full) {
+            u16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
+            *reinterpret_cast<u16x4*>(C) = o;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (n + e < p.N) C[e] = f2bf(v[e]);
+          }
+        }
+      }
+    }
+  }
+}
+
 template <int BM, int BN, int WR, int WC, int EPI, bool CONV>
 __global__ __launch_bounds__(WR* WC * 64) void gemm16_nt_kernel(const GemmParams p) {
   using Cfg = GemmCfg<BM, BN, WR, WC>;
@@ -440,98 +537,234 @@ __global__ __launch_bounds__(WR* WC * 64) void gemm16_nt_kernel(const GemmParams
     }
   }
 
-  // ---- epilogue: lane owns row m and 4 consecutive columns per (i, j) ----
-  const int64_t mw = m0 + wr * (BM / WR);
-  const int64_t nw = n0 + wc * (BN / WC);
-  const bool vec = (p.ldc % 4 == 0) && (((uintptr_t)p.c & 15) == 0);
+  gemm16_epilogue<TM, TN, EPI>(p, acc, m0 + wr * (BM / WR), n0 + wc * (BN / WC), r16, q);
+}
+
+// ---------------------------------------------------------------------------
+// 256 x 256 tile, 8 phases per pair of K tiles ("ping-pong"): the default for the big token-side projections.
+//
+// The kernels above issue {stage next tile; read fragments; 64 MFMAs; vmcnt(0) + barrier} per K tile: both waves of a SIMD
+// read LDS at the same time and then fight for the matrix core at the same time, and every tile boundary drains the
+// LDS-DMA queue.  Here (cdna_hip_programming.md, "The 256^2 8-phase template"):
+//   * a K tile is FOUR phases of {ds_read one fragment sub-tile; issue one half-tile of LDS-DMA; counted vmcnt; s_barrier;
+//     16 MFMAs = one 64 x 32 quadrant of the wave's 128 x 64 output; s_barrier};
+//   * the lower wave row (wr = 1, waves 4-7: the second wave of every SIMD) runs ONE BARRIER BEHIND the upper one, so on
+//     each SIMD one wave's MFMA cluster always overlaps the other wave's LDS reads and DMA issue;
+//   * the DMA queue is never drained inside the loop: `s_waitcnt vmcnt(8)` leaves the four newest half-tiles in flight
+//     across the barriers (raw s_barrier: __syncthreads() would add vmcnt(0)).
+// LDS image (128 KiB): 2 K-tile buffers x 4 slots of 128 rows x 128 B, a slot = what one phase of all 8 waves reads:
+//     A-mq: rows {64 mq .. +64} of both 128-row wave rows      W-nq: columns {32 nq .. +32} of all four 64-column wave columns
+// Hazards (phases counted per wave row; P1..P4 of K tile kt, buffer kt & 1):
+//     reads   P1: A-mq0, W-nq0   P2: W-nq1   P3: A-mq1   P4: none (W-nq0 is still in registers)
+//     stages  P1: W-nq1(kt+1)    P2: A-mq1(kt+1)    P3: A-mq0(kt+2)    P4: W-nq0(kt+2)
+//   WAR: a slot is restaged two or more phases after the phase that read it (both wave rows have retired those reads by
+//        then: lgkmcnt(0) follows the first barrier of the reading phase, the staggered row is one barrier later).
+//   RAW: the wait of phase p (before its first barrier) retires everything but the 4 newest half-tiles, which always
+//        includes every slot phase p+1 reads; the reader passes at least one more barrier than any waiter.
+// ---------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm8p_nt_kernel(const GemmParams p) {
+  constexpr int BUF_BYTES = 65536, SLOT_BYTES = 16384;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int tm, tn;
+  gemm_tile_coords(p, tm, tn);
+  const int64_t m0 = (int64_t)tm * 256;
+  const int64_t n0 = (int64_t)tn * 256;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int r16 = lane & 15, q = lane >> 4;
+
+  // ---- LDS-DMA roles: instruction t of wave w fills slot rows 8 (2 w + t) .. +8; lane -> row (lane >> 3), 16-B position
+  // (lane & 7) which holds logical chunk (lane & 7) ^ ((row >> 1) & 7).  Per-lane state is the (clamped) global row of
+  // each of the 8 instructions; the source is  uniform base + K offset (SGPRs)  +  row * row-bytes + swizzle (32-bit VGPR) ----
+  int arow[2][2], wrow[2][2];  // [mq | nq][t]
+  unsigned swz[2];
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int64_t m = mw + i * 16 + r16;
-    if (m >= p.M) continue;
-    const float* grow = nullptr;
-    if constexpr (EPI == LCV_EPI_GATE_RESIDUAL) {
-      if (p.gate) grow = p.gate + (m / p.rows_per_frame) * p.mod_stride;
-    }
-    if constexpr (EPI == LCV_EPI_SWIGLU) {
-      // W rows interleaved [32 gate | 32 up]: within a 64-row block, 16-wide tiles 0,1 are gate and 2,3 their up partners
-      bf16_t* C = (bf16_t*)p.c + m * p.ldc;
+  for (int t = 0; t < 2; ++t) {
+    const int srow = 8 * (2 * wave + t) + (lane >> 3);
+    swz[t] = (unsigned)(((lane & 7) ^ ((srow >> 1) & 7)) * 16);
 #pragma unroll
-      for (int jb = 0; jb < TN / 4; ++jb)
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int64_t ng = nw + jb * 64 + 16 * u + 4 * q;
-          if (ng >= p.N) continue;
-          const int64_t f = (nw + jb * 64) / 2 + 16 * u + 4 * q;
-          u16x4 o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float bg = p.bias ? bf2f(p.bias[ng + e]) : 0.f;
-            const float bu = p.bias ? bf2f(p.bias[ng + 32 + e]) : 0.f;
-            const float gv = bfround(acc[i][4 * jb + u][e] + bg);
-            const float uv = bfround(acc[i][4 * jb + 2 + u][e] + bu);
-            o[e] = f2bf(bfround(silu_f(gv)) * uv);
-          }
-          if (vec) *reinterpret_cast<u16x4*>(C + f) = o;
-          else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) C[f + e] = o[e];
-          }
-        }
-    } else {
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int64_t n = nw + j * 16 + 4 * q;
-        if (n >= p.N) continue;
-        const bool full = vec && (n + 3 < p.N);
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e];
-        if (p.bias) {
-          if (full) {
-            const u16x4 b4 = *reinterpret_cast<const u16x4*>(p.bias + n);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += bf2f(b4[e]);
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (n + e < p.N) v[e] += bf2f(p.bias[n + e]);
-          }
-        }
-        if constexpr (EPI == LCV_EPI_GATE_RESIDUAL) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (n + e < p.N) v[e] = bf2f(p.resid[m * p.ldc + n + e]) + (grow ? grow[n + e] : 1.0f) * bfround(v[e]);
-        } else if constexpr (EPI == LCV_EPI_GELU_TANH) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(bfround(v[e]));
-        } else if constexpr (EPI == LCV_EPI_SILU) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = silu_f(bfround(v[e]));
-        }
-        if (p.out_f32) {
-          float* C = (float*)p.c + m * p.ldc + n;
-          if (full) *reinterpret_cast<f32x4*>(C) = f32x4{v[0], v[1], v[2], v[3]};
-          else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (n + e < p.N) C[e] = v[e];
-          }
-        } else {
-          bf16_t* C = (bf16_t*)p.c + m * p.ldc + n;
-          if (full) {
-            u16x4 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
-            *reinterpret_cast<u16x4*>(C) = o;
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (n + e < p.N) C[e] = f2bf(v[e]);
-          }
-        }
-      }
+    for (int h = 0; h < 2; ++h) {
+      int64_t g = m0 + (srow >> 6) * 128 + h * 64 + (srow & 63);
+      arow[h][t] = (int)(g > p.M - 1 ? p.M - 1 : g);
+      g = n0 + (srow >> 5) * 64 + h * 32 + (srow & 31);
+      wrow[h][t] = (int)(g > p.N - 1 ? p.N - 1 : g);
     }
   }
+  auto stage_a = [&](auto mq_c, int kts, int buf) {
+    constexpr int mq = decltype(mq_c)::value;
+    const bool lora = kts >= p.nk1;  // the rank-r pair (a2, w2) supplies the last nk2 K tiles
+    const char* base = lora ? (const char*)p.a2 + (int64_t)(kts - p.nk1) * 128 : (const char*)p.a + (int64_t)kts * 128;
+    const unsigned ldb = (unsigned)(lora ? p.lda2 : p.lda) * 2u;
+    unsigned char* dst = smem + buf * BUF_BYTES + mq * SLOT_BYTES + wave * 2048;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+      __builtin_amdgcn_global_load_lds((gbl_void*)(base + ((unsigned)arow[mq][t] * ldb + swz[t])), (lds_void*)(dst + t * 1024),
+                                       16, 0, 0);
+  };
+  auto stage_w = [&](auto nq_c, int kts, int buf) {
+    constexpr int nq = decltype(nq_c)::value;
+    const bool lora = kts >= p.nk1;
+    const char* base = lora ? (const char*)p.w2 + (int64_t)(kts - p.nk1) * 128 : (const char*)p.w + (int64_t)kts * 128;
+    const unsigned ldb = (unsigned)(lora ? p.ldw2 : p.ldw) * 2u;
+    unsigned char* dst = smem + buf * BUF_BYTES + (2 + nq) * SLOT_BYTES + wave * 2048;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+      __builtin_amdgcn_global_load_lds((gbl_void*)(base + ((unsigned)wrow[nq][t] * ldb + swz[t])), (lds_void*)(dst + t * 1024),
+                                       16, 0, 0);
+  };
+
+  // ---- fragment read addresses: slot row (wr * 64 + 16 i + r16) of an A slot, (wc * 32 + 16 j + r16) of a W slot ----
+  const int sw = (r16 >> 1) & 7;
+  int a_rd[2], w_rd[2];  // [ks]
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    a_rd[ks] = (wr * 64 + r16) * 128 + ((4 * ks + q) ^ sw) * 16;
+    w_rd[ks] = 2 * SLOT_BYTES + (wc * 32 + r16) * 128 + ((4 * ks + q) ^ sw) * 16;
+  }
+
+  f32x4v acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  bf16x8 af[4][2];     // [i][ks]      activations of the current 64-row half (B operand)
+  bf16x8 wf[2][2][2];  // [nq][j][ks]  weights of both 32-column halves (A operand)
+
+  using C0 = std::integral_constant<int, 0>;
+  using C1 = std::integral_constant<int, 1>;
+  // one phase.  P = 1..4, STAGE = issue this phase's half-tile, VM = vmcnt to wait for (-1: none); buf = buffer of K tile kt
+  // (wave-uniform; the fragment read bases a_rd / w_rd already point into it)
+  auto phase = [&](auto P_c, auto STAGE_c, auto VM_c, int kt, int buf) {
+    constexpr int P = decltype(P_c)::value, VM = decltype(VM_c)::value;
+    constexpr bool STAGE = decltype(STAGE_c)::value != 0;
+    if constexpr (P == 1 || P == 2) {
+      constexpr int nq = P - 1;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+          wf[nq][j][ks] = *reinterpret_cast<const bf16x8*>(smem + w_rd[ks] + nq * SLOT_BYTES + j * 2048);
+    }
+    if constexpr (P == 1 || P == 3) {
+      constexpr int mq = P == 1 ? 0 : 1;
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+          af[i][ks] = *reinterpret_cast<const bf16x8*>(smem + a_rd[ks] + mq * SLOT_BYTES + i * 2048);
+    }
+    if constexpr (STAGE) {
+      if constexpr (P == 1) stage_w(C1{}, kt + 1, buf ^ 1);
+      if constexpr (P == 2) stage_a(C1{}, kt + 1, buf ^ 1);
+      if constexpr (P == 3) stage_a(C0{}, kt + 2, buf);
+      if constexpr (P == 4) stage_w(C0{}, kt + 2, buf);
+    }
+    if constexpr (VM >= 0) wait_vmcnt<VM>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+    constexpr int mq = (P >= 3) ? 1 : 0;
+    constexpr int nq = (P == 2 || P == 3) ? 1 : 0;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[4 * mq + i][2 * nq + j] =
+              __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nq][j][ks], af[i][ks], acc[4 * mq + i][2 * nq + j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+  };
+  using V8 = std::integral_constant<int, 8>;
+  using V6 = std::integral_constant<int, 6>;
+  using V4 = std::integral_constant<int, 4>;
+  using V2 = std::integral_constant<int, 2>;
+  using V0 = std::integral_constant<int, 0>;
+  using VN = std::integral_constant<int, -1>;
+  using P1 = std::integral_constant<int, 1>;
+  using P2 = std::integral_constant<int, 2>;
+  using P3 = std::integral_constant<int, 3>;
+  using P4 = std::integral_constant<int, 4>;
+  auto flip = [&]() {  // fragment read bases -> the other buffer
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) { a_rd[ks] ^= BUF_BYTES; w_rd[ks] ^= BUF_BYTES; }
+  };
+
+  // ---- prologue: the steady-state issue order A-mq0, W-nq0, W-nq1, A-mq1 of tile 0, then A-mq0, W-nq0 of tile 1 ----
+  const int nk = p.nk1 + p.nk2;  // >= 2, nk1 >= 2 (host-checked)
+  stage_a(C0{}, 0, 0);
+  stage_w(C0{}, 0, 0);
+  stage_w(C1{}, 0, 0);
+  stage_a(C1{}, 0, 0);
+  stage_a(C0{}, 1, 1);
+  stage_w(C0{}, 1, 1);
+  wait_vmcnt<8>();  // A-mq0 and W-nq0 of tile 0 have landed
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();  // the lower wave row runs one barrier behind
+
+  int kt = 0;
+  for (; kt < nk - 2; ++kt) {
+    const int buf = kt & 1;
+    phase(P1{}, C1{}, V8{}, kt, buf);
+    phase(P2{}, C1{}, V8{}, kt, buf);
+    phase(P3{}, C1{}, V8{}, kt, buf);
+    phase(P4{}, C1{}, V8{}, kt, buf);
+    flip();
+  }
+  {  // K tile nk-2: nothing left to stage for tile nk
+    const int buf = kt & 1;
+    phase(P1{}, C1{}, V8{}, kt, buf);
+    phase(P2{}, C1{}, V8{}, kt, buf);
+    phase(P3{}, C0{}, V6{}, kt, buf);
+    phase(P4{}, C0{}, V4{}, kt, buf);
+    flip();
+    ++kt;
+  }
+  {  // K tile nk-1
+    const int buf = kt & 1;
+    phase(P1{}, C0{}, V2{}, kt, buf);
+    phase(P2{}, C0{}, V0{}, kt, buf);
+    phase(P3{}, C0{}, VN{}, kt, buf);
+    phase(P4{}, C0{}, VN{}, kt, buf);
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();  // balance the stagger
+
+  gemm16_epilogue<8, 4, EPI>(p, acc, m0 + wr * 128, n0 + wc * 64, r16, q);
+}
+
+template <int EPI>
+static int launch_gemm8p(GemmParams& p, hipStream_t s) {
+  p.tiles_m = (int)((p.M + 255) / 256);
+  p.tiles_n = (int)((p.N + 255) / 256);
+  const size_t lds = 2 * 65536;
+  auto kern = gemm8p_nt_kernel<EPI>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      lcv_set_error("gemm_nt: cannot raise dynamic LDS to %zu", lds);
+      return LCV_EDEVICE;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), lds, s, p);
+  LCV_LAUNCH_CHECK("gemm8p_nt");
+  return LCV_OK;
 }
 
 template <int BM, int BN, int WR, int WC, int EPI, bool CONV>
@@ -581,8 +814,13 @@ static int dispatch_tile(GemmParams& p, hipStream_t s) {
   // LCV_GEMM_TILE = 6 | 7 forces 256 / 128 (16x16x32); 2 | 1 the same tiles on the 32x32x16 kernel (A/B runs, tests).
   const char* force = getenv("LCV_GEMM_TILE");
   int mode = (p.M >= 2048 && p.N >= 1024) ? 6 : 7;
+  // 8-phase ping-pong schedule on the same tile; its LDS-DMA sources are 32-bit byte offsets from the operand base
+  const bool ok8 = p.nk1 >= 2 && (uint64_t)p.M * p.lda * 2 < (1ull << 32) && (uint64_t)p.N * p.ldw * 2 < (1ull << 32) &&
+                   (p.nk2 == 0 || ((uint64_t)p.M * p.lda2 * 2 < (1ull << 32) && (uint64_t)p.N * p.ldw2 * 2 < (1ull << 32)));
+  if (mode == 6 && ok8) mode = 8;
   if (force) mode = force[0] - '0';
-  if (mode == 6) return launch_gemm16<256, 256, 2, 4, EPI, false>(p, s);
+  if (mode == 8 && ok8) return launch_gemm8p<EPI>(p, s);
+  if (mode == 6 || mode == 8) return launch_gemm16<256, 256, 2, 4, EPI, false>(p, s);
   if (mode == 7) return launch_gemm16<128, 128, 2, 2, EPI, false>(p, s);
   if (mode == 2) return launch_gemm<256, 256, 2, 4, EPI, false>(p, s);
   return launch_gemm<128, 128, 2, 2, EPI, false>(p, s);

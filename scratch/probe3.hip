@@ -2,10 +2,9 @@
 #include <stdio.h>
 __global__ void k(float* out) {
   int lane = threadIdx.x;
-  unsigned a = 100 + lane, b = 200 + lane;
-  asm volatile("" : "+v"(a)); asm volatile("" : "+v"(b));
-  auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
-  out[lane*2] = (float)r[0]; out[lane*2+1] = (float)r[1];
+  float a = 100 + lane, b = 200 + lane;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  out[lane*2] = a; out[lane*2+1] = b;
 }
 int main(){ float* d; hipMalloc(&d, 4*128); float h[128]; hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, 0, d); hipMemcpy(h,d,4*128,hipMemcpyDeviceToHost);
- for (int l : {0,1,31,32,33,63}) printf("lane %d: r0=%g r1=%g\n", l, h[2*l], h[2*l+1]); return 0; }
+ for (int l : {0,1,15,16,17,31,32,33,47,48,63}) printf("lane %d: a=%g b=%g\n", l, h[2*l], h[2*l+1]); return 0; }

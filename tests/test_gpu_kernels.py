@@ -119,7 +119,8 @@ def test_attention_strided_packed_qkv_and_spike():
     assert rel_l2(o.permute(0, 2, 1, 3), ref) < 6e-3
 
 
-@pytest.mark.parametrize("M,N,K,tile", [(300, 192, 128, "1"), (70, 64, 64, "1"), (2050, 1024, 256, "2"), (513, 768, 192, "2"), (700, 300, 1088, "2"), (2050, 1024, 256, "6"), (513, 768, 192, "6"), (700, 300, 1088, "6"), (300, 192, 128, "7"), (70, 64, 64, "7")])
+@pytest.mark.parametrize("M,N,K,tile", [(300, 192, 128, "1"), (70, 64, 64, "1"), (2050, 1024, 256, "2"), (513, 768, 192, "2"), (700, 300, 1088, "2"), (2050, 1024, 256, "6"), (513, 768, 192, "6"), (700, 300, 1088, "6"), (300, 192, 128, "7"), (70, 64, 64, "7"),
+                                          (2050, 1024, 256, "8"), (513, 768, 192, "8"), (700, 300, 1088, "8"), (300, 192, 128, "8")])
 def test_gemm_nt_bias(M, N, K, tile, monkeypatch):
     monkeypatch.setenv("LCV_GEMM_TILE", tile)
     ops, orc = _ops(), _orc()
@@ -131,7 +132,7 @@ def test_gemm_nt_bias(M, N, K, tile, monkeypatch):
     assert rel_l2(c32, orc.linear(a, w, b)) < 1e-5
 
 
-@pytest.mark.parametrize("tile", ["1", "7"])
+@pytest.mark.parametrize("tile", ["1", "7", "8"])
 def test_gemm_nt_lora_and_epilogues(tile, monkeypatch):
     monkeypatch.setenv("LCV_GEMM_TILE", tile)
     ops, orc = _ops(), _orc()
@@ -167,6 +168,27 @@ def test_gemm_nt_lora_and_epilogues(tile, monkeypatch):
     gte, up = orc.linear(a, w1, None, orc.bf16_round), orc.linear(a, w3, None, orc.bf16_round)
     ref = orc.bf16_round(orc.bf16_round(F.silu(gte)) * up)
     assert c.shape == (M, Fh) and rel_l2(c, ref) < 2e-3
+
+
+def test_gemm_8phase_matches_plain_schedule_bitwise(monkeypatch):
+    """The 8-phase ping-pong kernel (counted vmcnt, raw barriers, staggered wave rows) accumulates K in the same order on
+    the same MFMA as the one-barrier-per-tile kernel: any difference at all is a synchronisation bug (a fragment read
+    before its LDS-DMA landed, or a slot restaged under a reader).  Long K, many tiles, repeated launches."""
+    ops = _ops()
+    M, N, K = 4096 + 70, 2048 + 30, 4096
+    a = _randn(M, K, seed=61).to(DEV); w = _randn(N, K, seed=62, scale=0.05).to(DEV); b = _randn(N, seed=63).to(DEV)
+    monkeypatch.setenv("LCV_GEMM_TILE", "6")
+    ref = ops.gemm_nt(a, w, b)
+    monkeypatch.setenv("LCV_GEMM_TILE", "8")
+    for _ in range(5):
+        assert torch.equal(ops.gemm_nt(a, w, b), ref)
+    # with the rank-r pair as the last K tile
+    a2 = _randn(M, 64, seed=64).to(DEV); w2 = _randn(N, 64, seed=65, scale=0.05).to(DEV)
+    monkeypatch.setenv("LCV_GEMM_TILE", "6")
+    ref = ops.gemm_nt(a, w, b, a2=a2, w2=w2)
+    monkeypatch.setenv("LCV_GEMM_TILE", "8")
+    for _ in range(3):
+        assert torch.equal(ops.gemm_nt(a, w, b, a2=a2, w2=w2), ref)
 
 
 def test_linear_f32_smallm():
