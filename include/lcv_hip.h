@@ -87,6 +87,9 @@ int lcv_gate_residual_bwd(const void* y, const float* mod, const void* dout,
  * cs: [N_pos, D/2] float2 (cos, sin) table, row = pos_off + n (global position, so a
  * sequence-parallel shard passes its own offset); cs == NULL skips RoPE
  * (text cross-attention q/k norm).  RoPE pairs are interleaved (2i, 2i+1).
+ * q_scale (> 0, 1 = none) multiplies the q output before its single bf16 rounding: the self-attention
+ * path passes head_dim^-0.5 * log2(e) here and scale = ln 2 to lcv_attn_fwd/bwd, whose exponent is
+ * then q.k itself (same softmax, one multiply-subtract per score less).
  * Replaces upstream q_norm/k_norm/rope_3d inside Attention.forward
  * (attribute names: lora_experiment/scripts/run_lora_tta.py:142-168). */
 int lcv_qknorm_rope_fwd(const void* q_in, const void* k_in, const void* v_in,
@@ -96,10 +99,10 @@ int lcv_qknorm_rope_fwd(const void* q_in, const void* k_in, const void* v_in,
                         int64_t in_sb, int64_t in_sn,       /* q_in/k_in/v_in strides */
                         int64_t q_sb, int64_t q_sn,         /* q_out strides */
                         int64_t kv_sb, int64_t kv_sn,       /* k_out/v_out strides */
-                        int64_t pos_off, float eps, void* stream);
+                        int64_t pos_off, float eps, float q_scale, void* stream);
 /* Backward: given dq_out, dk_out (same addressing as q_out/k_out) and the
- * pre-norm q_in/k_in, writes dq_in, dk_in (strides din_*).  The norm weights are
- * frozen on this path (qk_norm tuning is out of scope). */
+ * pre-norm q_in/k_in, writes dq_in, dk_in (strides din_*); q_scale as in the forward.  The norm
+ * weights are frozen on this path (qk_norm tuning is out of scope). */
 int lcv_qknorm_rope_bwd(const void* q_in, const void* k_in,
                         const void* dq_out, const void* dk_out,
                         void* dq_in, void* dk_in,
@@ -109,7 +112,7 @@ int lcv_qknorm_rope_bwd(const void* q_in, const void* k_in,
                         int64_t q_sb, int64_t q_sn,
                         int64_t kv_sb, int64_t kv_sn,
                         int64_t din_sb, int64_t din_sn,
-                        int64_t pos_off, float eps, void* stream);
+                        int64_t pos_off, float eps, float q_scale, void* stream);
 
 /* ---- flash attention (dense, non-causal, head_dim 128, bf16, fp32 acc) */
 /* o[b,n,h,:] = softmax(q k^T * scale) v ; q: Nq rows, k/v: Nk rows.

@@ -158,7 +158,7 @@ extern "C" int lcv_gate_residual_fwd(const void* x, const void* y, const float* 
 // token's 64 (cos,sin) pairs are loaded once and reused by every head of q and k.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void norm_rope_vec(const bf16_t* src, bf16_t* dst, const float (&w)[8],
-                                              const float (&cs)[8], bool do_rope, float eps) {
+                                              const float (&cs)[8], bool do_rope, float eps, float out_scale) {
   float f[8];
   unpack8(*reinterpret_cast<const u16x8*>(src), f);
   float ss = 0.f;
@@ -186,6 +186,10 @@ __device__ __forceinline__ void norm_rope_vec(const bf16_t* src, bf16_t* dst, co
 #pragma unroll
     for (int i = 0; i < 8; ++i) o[i] = f[i];
   }
+  // out_scale != 1 (q only): the attention scale head_dim^-0.5 * log2(e) folded in BEFORE the one bf16 rounding of the
+  // output, so the attention kernel's exponent is q.k itself (attn_fwd.hip, UNIT)
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] *= out_scale;
   *reinterpret_cast<u16x8*>(dst) = pack8(o);
 }
 
@@ -194,7 +198,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_fwd_kernel(
     bf16_t* __restrict__ q_out, bf16_t* __restrict__ k_out, bf16_t* __restrict__ v_out,
     const bf16_t* __restrict__ wq, const bf16_t* __restrict__ wk, const float* __restrict__ cs_tab,
     int H, int64_t in_sb, int64_t in_sn, int64_t q_sb, int64_t q_sn, int64_t kv_sb, int64_t kv_sn,
-    int64_t pos_off, float eps) {
+    int64_t pos_off, float eps, float q_scale) {
   const int64_t n = blockIdx.x, b = blockIdx.y;
   const int sub = threadIdx.x & 15;   // 8-element slice of the head vector
   const int hl = threadIdx.x >> 4;    // head within the pass
@@ -215,8 +219,8 @@ __global__ __launch_bounds__(256) void qknorm_rope_fwd_kernel(
     const int h = h0 + hl;
     if (h >= H) continue;  // whole 16-lane groups drop out together, so the in-group shuffles stay valid
     const int64_t off = (int64_t)h * 128 + sub * 8;
-    if (q_in) norm_rope_vec(q_in + in_base + off, q_out + b * q_sb + n * q_sn + off, wqf, cs, do_rope, eps);
-    if (k_in) norm_rope_vec(k_in + in_base + off, k_out + b * kv_sb + n * kv_sn + off, wkf, cs, do_rope, eps);
+    if (q_in) norm_rope_vec(q_in + in_base + off, q_out + b * q_sb + n * q_sn + off, wqf, cs, do_rope, eps, q_scale);
+    if (k_in) norm_rope_vec(k_in + in_base + off, k_out + b * kv_sb + n * kv_sn + off, wkf, cs, do_rope, eps, 1.0f);
     if (v_out) {
       *reinterpret_cast<u16x8*>(v_out + b * kv_sb + n * kv_sn + off) =
           *reinterpret_cast<const u16x8*>(v_in + in_base + off);
@@ -228,8 +232,9 @@ extern "C" int lcv_qknorm_rope_fwd(const void* q_in, const void* k_in, const voi
                                    void* k_out, void* v_out, const void* wq, const void* wk,
                                    const void* cs, int64_t B, int64_t N, int64_t H, int64_t in_sb,
                                    int64_t in_sn, int64_t q_sb, int64_t q_sn, int64_t kv_sb,
-                                   int64_t kv_sn, int64_t pos_off, float eps, void* stream) {
+                                   int64_t kv_sn, int64_t pos_off, float eps, float q_scale, void* stream) {
   LCV_CHECK_ARG((q_in || k_in) && wq && wk, "qknorm_rope_fwd: null pointer");
+  LCV_CHECK_ARG(q_scale > 0.f, "qknorm_rope_fwd: q_scale must be positive (1 = none)");
   LCV_CHECK_ARG(!q_in || q_out, "qknorm_rope_fwd: q_out missing");
   LCV_CHECK_ARG(!k_in || k_out, "qknorm_rope_fwd: k_out missing");
   LCV_CHECK_ARG(H > 0, "qknorm_rope_fwd: H must be positive");
@@ -241,7 +246,7 @@ extern "C" int lcv_qknorm_rope_fwd(const void* q_in, const void* k_in, const voi
                      (hipStream_t)stream, (const bf16_t*)q_in, (const bf16_t*)k_in, (const bf16_t*)v_in,
                      (bf16_t*)q_out, (bf16_t*)k_out, copy_v ? (bf16_t*)v_out : nullptr, (const bf16_t*)wq,
                      (const bf16_t*)wk, (const float*)cs, (int)H, in_sb, in_sn, q_sb, q_sn, kv_sb, kv_sn,
-                     pos_off, eps);
+                     pos_off, eps, q_scale);
   LCV_LAUNCH_CHECK("qknorm_rope_fwd");
   return LCV_OK;
 }

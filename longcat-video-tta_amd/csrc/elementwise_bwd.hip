@@ -171,10 +171,12 @@ extern "C" int lcv_gate_residual_bwd(const void* y, const float* mod, const void
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void norm_rope_bwd_vec(const bf16_t* xin, const bf16_t* dout, bf16_t* dxin,
                                                   const float (&w)[8], const float (&cs)[8], bool do_rope,
-                                                  float eps) {
+                                                  float eps, float out_scale) {
   float x[8], d[8];
   unpack8(*reinterpret_cast<const u16x8*>(xin), x);
   unpack8(*reinterpret_cast<const u16x8*>(dout), d);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) d[i] *= out_scale;  // the forward multiplied its output by out_scale
   float ss = 0.f;
 #pragma unroll
   for (int i = 0; i < 8; ++i) ss += x[i] * x[i];
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(
     const bf16_t* __restrict__ dk_out, bf16_t* __restrict__ dq_in, bf16_t* __restrict__ dk_in,
     const bf16_t* __restrict__ wq, const bf16_t* __restrict__ wk, const float* __restrict__ cs_tab, int H,
     int64_t in_sb, int64_t in_sn, int64_t q_sb, int64_t q_sn, int64_t kv_sb, int64_t kv_sn, int64_t din_sb,
-    int64_t din_sn, int64_t pos_off, float eps) {
+    int64_t din_sn, int64_t pos_off, float eps, float q_scale) {
   const int64_t n = blockIdx.x, b = blockIdx.y;
   const int sub = threadIdx.x & 15;
   const int hl = threadIdx.x >> 4;
@@ -241,10 +243,10 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(
     const int64_t off = (int64_t)h * 128 + sub * 8;
     if (q_in)
       norm_rope_bwd_vec(q_in + b * in_sb + n * in_sn + off, dq_out + b * q_sb + n * q_sn + off,
-                        dq_in + b * din_sb + n * din_sn + off, wqf, cs, do_rope, eps);
+                        dq_in + b * din_sb + n * din_sn + off, wqf, cs, do_rope, eps, q_scale);
     if (k_in)
       norm_rope_bwd_vec(k_in + b * in_sb + n * in_sn + off, dk_out + b * kv_sb + n * kv_sn + off,
-                        dk_in + b * din_sb + n * din_sn + off, wkf, cs, do_rope, eps);
+                        dk_in + b * din_sb + n * din_sn + off, wkf, cs, do_rope, eps, 1.0f);
   }
 }
 
@@ -252,7 +254,7 @@ extern "C" int lcv_qknorm_rope_bwd(const void* q_in, const void* k_in, const voi
                                    void* dq_in, void* dk_in, const void* wq, const void* wk, const void* cs,
                                    int64_t B, int64_t N, int64_t H, int64_t in_sb, int64_t in_sn, int64_t q_sb,
                                    int64_t q_sn, int64_t kv_sb, int64_t kv_sn, int64_t din_sb, int64_t din_sn,
-                                   int64_t pos_off, float eps, void* stream) {
+                                   int64_t pos_off, float eps, float q_scale, void* stream) {
   LCV_CHECK_ARG((q_in || k_in) && wq && wk, "qknorm_rope_bwd: null pointer");
   LCV_CHECK_ARG(!q_in || (dq_out && dq_in), "qknorm_rope_bwd: q gradients missing");
   LCV_CHECK_ARG(!k_in || (dk_out && dk_in), "qknorm_rope_bwd: k gradients missing");
@@ -261,7 +263,7 @@ extern "C" int lcv_qknorm_rope_bwd(const void* q_in, const void* k_in, const voi
   hipLaunchKernelGGL(qknorm_rope_bwd_kernel, dim3((unsigned)N, (unsigned)B), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)q_in, (const bf16_t*)k_in, (const bf16_t*)dq_out, (const bf16_t*)dk_out,
                      (bf16_t*)dq_in, (bf16_t*)dk_in, (const bf16_t*)wq, (const bf16_t*)wk, (const float*)cs,
-                     (int)H, in_sb, in_sn, q_sb, q_sn, kv_sb, kv_sn, din_sb, din_sn, pos_off, eps);
+                     (int)H, in_sb, in_sn, q_sb, q_sn, kv_sb, kv_sn, din_sb, din_sn, pos_off, eps, q_scale);
   LCV_LAUNCH_CHECK("qknorm_rope_bwd");
   return LCV_OK;
 }

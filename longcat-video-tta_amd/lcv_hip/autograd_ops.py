@@ -231,8 +231,10 @@ class _SelfAttentionFn(torch.autograd.Function):
     def forward(ctx, qkv, wq, wk, cs, scale, n_cond, eps):
         B, N, _, H, D = qkv.shape
         qk = torch.empty((B, N, 2, H, D), dtype=BF16, device=qkv.device)  # roped q, k (qkv kept for the norm backward)
-        ops.qknorm_rope(qkv[:, :, 0], qkv[:, :, 1], None, qk[:, :, 0], qk[:, :, 1], None, wq, wk, cs, 0, eps)
-        o, lses = _attend_regions(qk[:, :, 0], qk[:, :, 1], qkv[:, :, 2], scale, n_cond, True)
+        # q is produced pre-scaled into log2 units (ops.log2_qscale) and the attention kernels run with scale = ln 2
+        ops.qknorm_rope(qkv[:, :, 0], qkv[:, :, 1], None, qk[:, :, 0], qk[:, :, 1], None, wq, wk, cs, 0, eps,
+                        q_scale=ops.log2_qscale(scale))
+        o, lses = _attend_regions(qk[:, :, 0], qk[:, :, 1], qkv[:, :, 2], ops.LN2, n_cond, True)
         ctx.save_for_backward(qkv, qk, o, wq, wk, cs, *lses)
         ctx.args = (scale, n_cond, eps)
         return o
@@ -250,15 +252,16 @@ class _SelfAttentionFn(torch.autograd.Function):
         dq, dk, dv = dqkv_r[:, :, 0], dqkv_r[:, :, 1], dqkv_r[:, :, 2]
         if n_cond > 0:
             ops.attention_bwd(q[:, :n_cond], k[:, :n_cond], v[:, :n_cond], o[:, :n_cond], do[:, :n_cond], lses[0],
-                              dq[:, :n_cond], dk[:, :n_cond], dv[:, :n_cond], scale, accumulate_kv=False)
+                              dq[:, :n_cond], dk[:, :n_cond], dv[:, :n_cond], ops.LN2, accumulate_kv=False)
             if N > n_cond:
                 # noise queries see every key: dk/dv of the cond rows receive a second contribution
                 ops.attention_bwd(q[:, n_cond:], k, v, o[:, n_cond:], do[:, n_cond:], lses[1],
-                                  dq[:, n_cond:], dk, dv, scale, accumulate_kv=True)
+                                  dq[:, n_cond:], dk, dv, ops.LN2, accumulate_kv=True)
         else:
-            ops.attention_bwd(q, k, v, o, do, lses[0], dq, dk, dv, scale, accumulate_kv=False)
+            ops.attention_bwd(q, k, v, o, do, lses[0], dq, dk, dv, ops.LN2, accumulate_kv=False)
         dqkv = torch.empty_like(qkv)
-        ops.qknorm_rope_bwd(qkv[:, :, 0], qkv[:, :, 1], dq, dk, dqkv[:, :, 0], dqkv[:, :, 1], wq, wk, cs, 0, eps)
+        ops.qknorm_rope_bwd(qkv[:, :, 0], qkv[:, :, 1], dq, dk, dqkv[:, :, 0], dqkv[:, :, 1], wq, wk, cs, 0, eps,
+                            q_scale=ops.log2_qscale(scale))
         dqkv[:, :, 2].copy_(dv)
         return dqkv, None, None, None, None, None, None
 
@@ -271,8 +274,8 @@ def self_attention(qkv, wq, wk, cs, scale, n_cond, eps, return_kv=False):
             raise LcvError("self_attention: return_kv is an inference-only path")
         return _SelfAttentionFn.apply(qkv, wq, wk, cs, scale, n_cond, eps), None
     q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
-    ops.qknorm_rope(q, k, None, q, k, None, wq, wk, cs, 0, eps)  # in place on the GEMM output
-    o, _ = _attend_regions(q, k, v, scale, n_cond, False)
+    ops.qknorm_rope(q, k, None, q, k, None, wq, wk, cs, 0, eps, q_scale=ops.log2_qscale(scale))  # in place on the GEMM output
+    o, _ = _attend_regions(q, k, v, ops.LN2, n_cond, False)
     kv = (k.contiguous(), v.contiguous()) if return_kv else None
     return o, kv
 
@@ -288,8 +291,9 @@ def cached_attention(qkv, k_c, v_c, wq, wk, cs, scale, eps):
     kbuf[:, :n_c].copy_(k_c if k_c.shape[0] == B else k_c.expand(B, -1, -1, -1))
     vbuf[:, :n_c].copy_(v_c if v_c.shape[0] == B else v_c.expand(B, -1, -1, -1))
     q = qkv[:, :, 0]
-    ops.qknorm_rope(q, qkv[:, :, 1], qkv[:, :, 2], q, kbuf[:, n_c:], vbuf[:, n_c:], wq, wk, cs, n_c, eps)
-    o, _ = ops.attention(q, kbuf, vbuf, scale)
+    ops.qknorm_rope(q, qkv[:, :, 1], qkv[:, :, 2], q, kbuf[:, n_c:], vbuf[:, n_c:], wq, wk, cs, n_c, eps,
+                    q_scale=ops.log2_qscale(scale))
+    o, _ = ops.attention(q, kbuf, vbuf, ops.LN2)
     return o
 
 

@@ -74,8 +74,9 @@ def gate_residual(x: torch.Tensor, y: torch.Tensor, mod: Optional[torch.Tensor],
 def qknorm_rope(q_in: Optional[torch.Tensor], k_in: Optional[torch.Tensor], v_in: Optional[torch.Tensor],
                 q_out: Optional[torch.Tensor], k_out: Optional[torch.Tensor], v_out: Optional[torch.Tensor],
                 wq: torch.Tensor, wk: torch.Tensor, cs: Optional[torch.Tensor], pos_off: int = 0,
-                eps: float = 1e-6) -> None:
-    """All tensors are [B, N, H, 128] views with contiguous (H, D); in-place allowed (out is in)."""
+                eps: float = 1e-6, q_scale: float = 1.0) -> None:
+    """All tensors are [B, N, H, 128] views with contiguous (H, D); in-place allowed (out is in).
+    q_scale multiplies the q output before its bf16 rounding (see `LOG2_QSCALE`)."""
     ref = q_in if q_in is not None else k_in
     B, N, H, D = ref.shape
     if D != 128:
@@ -104,7 +105,17 @@ def qknorm_rope(q_in: Optional[torch.Tensor], k_in: Optional[torch.Tensor], v_in
     ko = kvs[0] if kvs else ref
     call("lcv_qknorm_rope_fwd", _ptr(q_in), _ptr(k_in), _ptr(v_in), _ptr(q_out), _ptr(k_out), _ptr(v_out),
          _ptr(wq), _ptr(wk), _ptr(cs), B, N, H, ins[0].stride(0), ins[0].stride(1), qo.stride(0), qo.stride(1),
-         ko.stride(0), ko.stride(1), pos_off, eps, _stream())
+         ko.stride(0), ko.stride(1), pos_off, eps, q_scale, _stream())
+
+
+# The self-attention path folds its softmax scale into q: q' = q * scale * log2(e) (in the q norm/RoPE kernel, before
+# the bf16 rounding) and calls the attention kernels with scale = ln 2, so that exp(scale * q'.k) == exp2(q'.k).
+LOG2E = 1.4426950408889634
+LN2 = 0.6931471805599453
+
+
+def log2_qscale(scale: float) -> float:
+    return scale * LOG2E
 
 
 # -------------------------------------------------------------- attention ---
@@ -290,7 +301,7 @@ def gate_residual_bwd(y, mod, dout, gate_idx, T, need_dmod=False):
     return dy, dmod
 
 
-def qknorm_rope_bwd(q_in, k_in, dq_out, dk_out, dq_in, dk_in, wq, wk, cs, pos_off=0, eps=1e-6):
+def qknorm_rope_bwd(q_in, k_in, dq_out, dk_out, dq_in, dk_in, wq, wk, cs, pos_off=0, eps=1e-6, q_scale=1.0):
     ref = q_in if q_in is not None else k_in
     B, N, H, D = ref.shape
     go = dq_out if dq_out is not None else dk_out
@@ -301,7 +312,7 @@ def qknorm_rope_bwd(q_in, k_in, dq_out, dk_out, dq_in, dk_in, wq, wk, cs, pos_of
             raise _lib.LcvError("qknorm_rope_bwd: (H, D) must be contiguous")
     call("lcv_qknorm_rope_bwd", _ptr(q_in), _ptr(k_in), _ptr(dq_out), _ptr(dk_out), _ptr(dq_in), _ptr(dk_in),
          _ptr(wq), _ptr(wk), _ptr(cs), B, N, H, ref.stride(0), ref.stride(1), go.stride(0), go.stride(1),
-         gk.stride(0), gk.stride(1), gi.stride(0), gi.stride(1), pos_off, eps, _stream())
+         gk.stride(0), gk.stride(1), gi.stride(0), gi.stride(1), pos_off, eps, q_scale, _stream())
 
 
 def attention_bwd(q, k, v, o, do, lse, dq, dk, dv, scale, accumulate_kv=False):

@@ -147,9 +147,10 @@ class Attention(nn.Module):
         B, N, _, H, D = qkv.shape
         cs = self.rope_3d.table((sp.num_frames, shape[1], shape[2]), qkv.device)
         q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
-        ops.qknorm_rope(q, k, None, q, k, None, self.q_norm.weight, self.k_norm.weight, cs, sp.token_offset, self.q_norm.eps)
+        ops.qknorm_rope(q, k, None, q, k, None, self.q_norm.weight, self.k_norm.weight, cs, sp.token_offset, self.q_norm.eps,
+                        q_scale=ops.log2_qscale(self.scale))
         k_full, v_full = sp.all_gather_kv(k.contiguous(), v.contiguous())
-        o, _ = ops.attention(q, k_full, v_full, self.scale)
+        o, _ = ops.attention(q, k_full, v_full, ops.LN2)
         return self.proj(o.view(B, N, H * D))
 
     def forward_with_kv_cache(self, x, shape=None, num_cond_latents=None, kv_cache=None):

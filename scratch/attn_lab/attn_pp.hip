@@ -30,7 +30,7 @@ struct AttnFwdParams {
   int H;
   int64_t q_sb, q_sn, q_sh, k_sb, k_sn, k_sh, v_sb, v_sn, v_sh, o_sb, o_sn, o_sh;
   float scale, scale_log2e;
-  int gx, xcd_remap;  // q-blocks per (b,h); head-per-XCD block order when (B*H) % 8 == 0
+  int gx, xcd_remap, prio_all;  // q-blocks per (b,h); head-per-XCD block order when (B*H) % 8 == 0
 };
 
 #define RESCALE_THR 6.0f  // log2 units: the running max may lag by up to 2^6 before O and l are rescaled
@@ -69,22 +69,37 @@ __device__ __forceinline__ int tile_off(int row, int ch) {
 // VAR bit 0: K/V tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4; the swizzle is applied on the SOURCE column,
 //            the destination is lane-linear) from per-lane pointers that advance by one tile per iteration: no staging
 //            registers, no ds_write, no per-tile 64-bit address arithmetic.
-//            (+3.6 % at N = 46 800.  Tried and dropped: row sums on the matrix core with an all-ones A operand, -3.6 %;
-//            a three-stage {QK^T | softmax | PV} ping-pong with waves 4-7 one stage behind, raw barriers and counted
-//            vmcnt: -1 %; the 16x16x32 MFMA shape: -10 % (this loop is vector-issue bound and that shape doubles the
-//            MFMA issue slots).  Sources of the dropped variants: scratch/tried/.)
+//            (+3.6 % at N = 46 800.  Tried and dropped: row sums on the matrix core with an all-ones A operand, -3.6 %.)
 typedef __attribute__((address_space(1))) void gbl_void_t;
 typedef __attribute__((address_space(3))) void lds_void_t;
+
+// LDS-DMA issued from an asm statement: the compiler then keeps no record of a pending LDS write, so it adds no
+// `s_waitcnt vmcnt(0)` of its own in front of the ds_read_b64_tr_b16 that follow (it does for the builtin form, which drains
+// the whole prefetch queue at the head of every PV stage).  Completion is counted by hand (cdna_hip_programming.md §5.7).
+__device__ __forceinline__ void glds16_asm(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst)
+      : "memory");
+}
+
+__device__ unsigned long long* g_dbg = nullptr;  // [2 waves][256] s_memtime stamps of block g_dbg_block
+__device__ int g_dbg_block = 0;
+#define DBG_MAX 256
 
 template <int NWAVES, int PRIO, bool XATTN, int VAR>
 __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnFwdParams p) {
   constexpr bool DMA = (VAR & 1) != 0;
-  // VAR bit 1: the caller pre-scaled Q so that Q.K is already the exponent in log2 units (scale * log2(e) == 1: the
-  // self-attention path folds head_dim^-0.5 * log2(e) into the q RMSNorm/RoPE kernel before ITS bf16 rounding).  The score
-  // accumulators then START at -running_max (a 16-register vector that changes only on a rescale) instead of 0, and
-  // P = exp2(accumulator) needs no per-element multiply-subtract: 31 fewer vector instructions per tile in a loop whose
-  // vector instructions do not hide behind its MFMAs.
-  constexpr bool UNIT = (VAR & 2) != 0;
+  // VAR bit 1 (with bit 0): three-stage ping-pong.  A tile is {QK^T | softmax | PV}, one raw s_barrier after each stage, and
+  // waves 4-7 (the second wave of every SIMD) run ONE STAGE BEHIND waves 0-3, so a SIMD always pairs
+  // (QK^T, PV) / (softmax, QK^T) / (PV, softmax): the vector-unit stage of one wave sits beside a matrix stage of the other
+  // instead of both waves exponentiating and then both queueing on the matrix core.  The K tile t+2 is issued at the start
+  // of PV(t) and V(t+1) at the start of softmax(t) (their buffers were last read two stages earlier by the trailing
+  // waves); counted vmcnt, never 0 inside the loop.
+  constexpr bool PP = (VAR & 2) != 0;
+  static_assert(!PP || DMA, "the ping-pong schedule stages by LDS-DMA");
   static_assert(!DMA || NWAVES == 8, "LDS-DMA staging is laid out for 8 waves (2 K + 2 V instructions per wave)");
   constexpr int NT = NWAVES * 64;
   constexpr int QROWS = NWAVES * 32;
@@ -125,6 +140,12 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnFwdPara
     const bf16_t* qp = p.q + b * p.q_sb + qrow * p.q_sn + (int64_t)head * p.q_sh + 8 * h;
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
+    if constexpr ((VAR & 2) != 0) {
+      // make the compiler retire these loads HERE: it cannot see the asm LDS-DMA below, and a wait it placed at the first
+      // use inside the tile loop would count (and drain) the prefetch queue on every iteration
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(qf[ks]));
+    }
   }
 
   // ---- staging roles: thread copies chunks c = tid + i*NT (row = c>>4, ch = c&15) ----
@@ -159,7 +180,8 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnFwdPara
     if ((int64_t)t * 64 + 64 <= p.Nk) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)src[i], (lds_void_t*)(dst + 1024 * i), 16, 0, 0);
+        if constexpr (PP) glds16_asm(src[i], (unsigned)(uintptr_t)(dst + 1024 * i));
+        else __builtin_amdgcn_global_load_lds((gbl_void_t*)src[i], (lds_void_t*)(dst + 1024 * i), 16, 0, 0);
         src[i] += 64 * sn;
       }
     } else {  // ragged last tile: rows past Nk re-read the last key (masked below)
@@ -167,7 +189,8 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnFwdPara
       for (int i = 0; i < 2; ++i) {
         int64_t back = (int64_t)t * 64 + dma_row[i] - (p.Nk - 1);
         if (back < 0) back = 0;
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)(src[i] - back * sn), (lds_void_t*)(dst + 1024 * i), 16, 0, 0);
+        if constexpr (PP) glds16_asm(src[i] - back * sn, (unsigned)(uintptr_t)(dst + 1024 * i));
+        else __builtin_amdgcn_global_load_lds((gbl_void_t*)(src[i] - back * sn), (lds_void_t*)(dst + 1024 * i), 16, 0, 0);
       }
     }
   };
@@ -176,6 +199,22 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnFwdPara
   auto dma_tile = [&](int t, int buf) {
     dma_half(K_{}, t, buf);
     dma_half(V_{}, t, buf);
+  };
+  int dbg_n = 0;
+  const bool dbg_on = g_dbg != nullptr && (int)blockIdx.x == g_dbg_block && (wave == 0 || wave == NWAVES / 2);
+  auto stamp = [&]() {
+    if (dbg_on && dbg_n < DBG_MAX) {
+      const unsigned long long tnow = __builtin_amdgcn_s_memtime();
+      if (lane == 0) g_dbg[(wave ? DBG_MAX : 0) + dbg_n] = tnow;
+      ++dbg_n;
+    }
+  };
+  auto stage_barrier = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    stamp();
+    __builtin_amdgcn_s_barrier();
+    stamp();
+    __builtin_amdgcn_sched_barrier(0);
   };
   auto load_tile = [&](int64_t kv0) {
 #pragma unroll
@@ -212,15 +251,27 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnFwdPara
   for (int d = 0; d < 4; ++d)
 #pragma unroll
     for (int e = 0; e < 16; ++e) oacc[d][e] = 0.f;
-  float m_run = UNIT ? 0.f : -INFINITY;  // running max of the raw (unscaled) scores of this lane's query
-  f32x16 minit;                           // UNIT: -m_run in every element = the C operand of each tile's first score MFMA
-#pragma unroll
-  for (int e = 0; e < 16; ++e) minit[e] = 0.f;
+  float m_run = -INFINITY;  // running max of the raw (unscaled) scores of this lane's query
   float l_run = 0.f;        // this lane's partial row sum (its 32 of every 64 keys)
 
-  if (PRIO == 1 && wave >= NWAVES / 2) __builtin_amdgcn_s_setprio(1);  // static priority for the younger half
+  if (p.prio_all == 1) __builtin_amdgcn_s_setprio(1);
+  else if (p.prio_all == 2) __builtin_amdgcn_s_setprio(2);
+  else if (p.prio_all == 3) __builtin_amdgcn_s_setprio(3);
+  else if (p.prio_all == 4) { if (wave < NWAVES / 2) __builtin_amdgcn_s_setprio(1); }
+  else if (p.prio_all == 5) { if (wave >= NWAVES / 2) __builtin_amdgcn_s_setprio(1); }
   const int nt = (int)((p.Nk + 63) / 64);
-  {
+  if (PP) {  // issue order K(0), V(0), K(1): the steady-state order of the loop below
+    dma_half(K_{}, 0, 0);
+    dma_half(V_{}, 0, 0);
+    if (nt > 1) {
+      dma_half(K_{}, 1, 1);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // K(0) has landed
+    } else {
+      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    }
+    stage_barrier();
+    if (wave >= NWAVES / 2) stage_barrier();  // the trailing half runs one stage behind
+  } else {
     if (DMA) {
       dma_tile(0, 0);
     } else {
@@ -235,7 +286,7 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnFwdPara
   auto tile_body = [&](const int t, auto buf_c, auto last_c) {
     constexpr int buf = decltype(buf_c)::value;  // compile-time buffer: every LDS address is a fixed register + immediate
     constexpr bool has_next = !decltype(last_c)::value;
-    if (has_next) {
+    if (has_next && !PP) {
       if (DMA) dma_tile(t + 1, buf ^ 1);  // buf ^ 1 was last read in iteration t-1; every wave has passed its barrier
       else load_tile((int64_t)(t + 1) * 64);
     }
@@ -246,7 +297,7 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnFwdPara
     // ---- S^T = K Q^T : two 32-key blocks ----
     f32x16 s0, s1;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) { s0[e] = UNIT ? minit[e] : 0.f; s1[e] = UNIT ? minit[e] : 0.f; }
+    for (int e = 0; e < 16; ++e) { s0[e] = 0.f; s1[e] = 0.f; }
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
       const int co = 16 * ((2 * ks + h) ^ kf);
@@ -254,6 +305,14 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnFwdPara
       const bf16x8 a1 = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(kb + 32 * 256 + k_row_off + co);
       s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qf[ks], s0, 0, 0, 0);
       s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qf[ks], s1, 0, 0, 0);
+    }
+
+    if (PP) {  // end of the QK^T stage: V(t) (issued in softmax(t-1)) must have landed; K(t+1) may stay in flight
+      asm volatile("" : "+v"(s0), "+v"(s1));  // the score MFMAs stay in this stage, the softmax in the next
+      if (has_next) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      stage_barrier();
+      if (has_next) dma_half(V_{}, t + 1, buf ^ 1);  // V(t-1)'s buffer: the trailing half finished PV(t-1) one stage ago
     }
 
     // ---- mask keys past Nk (last tile only; wave-uniform branch) ----
@@ -281,50 +340,23 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnFwdPara
     // defer-max: rescale O / l only when some query's running max grows by more than 2^RESCALE_THR; otherwise keep the
     // old max (P <= 2^RESCALE_THR, harmless in fp32 sums and bf16 P).  The decision is wave-uniform and taken before
     // this tile's P exists and after the previous tile's PV finished, so nothing is ever scaled twice or not at all.
+    if (__builtin_amdgcn_ballot_w64((mx - m_run) * p.scale_log2e > RESCALE_THR) != 0ull) {
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.scale_log2e);  // first tile: exp2(-inf) = 0
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
+    }
+    const float mc = m_run * p.scale_log2e;
     float psum = 0.f;
-    if constexpr (UNIT) {
-      // the scores are already relative to the running max: mx > 0 is growth.  Tile 0 always takes the branch and sets
-      // the first real maximum (m_run starts at 0 with O = l = 0, so its alpha multiplies zeros).
-      if (__builtin_amdgcn_ballot_w64(mx > RESCALE_THR) != 0ull || t == 0) {
-        const float d = (t == 0) ? mx : fmaxf(mx, 0.f);
-        const float alpha = __builtin_amdgcn_exp2f(-d);
-        m_run += d;
-        l_run *= alpha;
 #pragma unroll
-        for (int dd = 0; dd < 4; ++dd)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) oacc[dd][e] *= alpha;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          s0[e] -= d;
-          s1[e] -= d;
-          minit[e] = -m_run;
-        }
-      }
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        s0[e] = __builtin_amdgcn_exp2f(s0[e]);
-        s1[e] = __builtin_amdgcn_exp2f(s1[e]);
-        psum += s0[e] + s1[e];
-      }
-    } else {
-      if (__builtin_amdgcn_ballot_w64((mx - m_run) * p.scale_log2e > RESCALE_THR) != 0ull) {
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.scale_log2e);  // first tile: exp2(-inf) = 0
-        m_run = m_new;
-        l_run *= alpha;
-#pragma unroll
-        for (int d = 0; d < 4; ++d)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
-      }
-      const float mc = m_run * p.scale_log2e;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        s0[e] = __builtin_amdgcn_exp2f(s0[e] * p.scale_log2e - mc);
-        s1[e] = __builtin_amdgcn_exp2f(s1[e] * p.scale_log2e - mc);
-        psum += s0[e] + s1[e];
-      }
+    for (int e = 0; e < 16; ++e) {
+      s0[e] = __builtin_amdgcn_exp2f(s0[e] * p.scale_log2e - mc);
+      s1[e] = __builtin_amdgcn_exp2f(s1[e] * p.scale_log2e - mc);
+      psum += s0[e] + s1[e];
     }
     l_run += psum;
 
@@ -336,6 +368,13 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnFwdPara
       pb[1][j] = (__bf16)s0[8 + j];
       pb[2][j] = (__bf16)s1[j];
       pb[3][j] = (__bf16)s1[8 + j];
+    }
+
+    if (PP) {  // end of the softmax stage: K(t+1) (issued in PV(t-1)) must have landed; V(t+1) may stay in flight
+      asm volatile("" : "+v"(pb[0]), "+v"(pb[1]), "+v"(pb[2]), "+v"(pb[3]));  // P is complete before the barrier
+      if (has_next) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      stage_barrier();
+      if (t + 2 < nt) dma_half(K_{}, t + 2, buf);  // K(t)'s buffer: the trailing half finished QK^T(t) one stage ago
     }
 
     // ---- O^T += V^T P^T ----
@@ -356,7 +395,13 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnFwdPara
     }
 
     if (has_next && !DMA) store_tile(buf ^ 1);
-    __syncthreads();
+    if (PP) {
+      asm volatile("" : "+v"(oacc[0]), "+v"(oacc[1]), "+v"(oacc[2]), "+v"(oacc[3]));  // the PV MFMAs stay in this stage
+      stage_barrier();
+    } else {
+      __syncthreads();
+      stamp();
+    }
   };
   {
     using B0 = std::integral_constant<int, 0>;
@@ -373,6 +418,7 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnFwdPara
       tile_body(t, B0{}, std::true_type{});
     }
   }
+  if (PP && wave < NWAVES / 2) stage_barrier();  // balance the stagger
 
   // ---- epilogue ----
   const float l_tot = half_sum(l_run);
@@ -421,6 +467,7 @@ extern "C" int lcv_attn_fwd(const void* q, const void* k, const void* v, void* o
   const unsigned gx = (unsigned)((Nq + NW * 32 - 1) / (NW * 32));
   const char* xe = getenv("LCV_ATTN_XCD");  // A/B knob: 0 disables the head-per-XCD block order
   p.gx = (int)gx;
+  { const char* pa = getenv("LCV_PRIO_ALL"); p.prio_all = pa ? pa[0] - '0' : 0; }
   p.xcd_remap = ((B * H) % 8 == 0 && gx >= 8 && !(xe && xe[0] == '0')) ? 1 : 0;
   const dim3 grid = p.xcd_remap ? dim3(gx * (unsigned)(H * B)) : dim3(gx, (unsigned)H, (unsigned)B);
   auto launch = [&](auto kern) -> int {
@@ -431,16 +478,14 @@ extern "C" int lcv_attn_fwd(const void* q, const void* k, const void* v, void* o
     hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, (hipStream_t)stream, p);
     return LCV_OK;
   };
-  const char* ve = getenv("LCV_ATTN_VAR");  // A/B knob: 0 = register-staged K/V tiles instead of LDS-DMA
-  const int var = ve ? (ve[0] - '0') & 1 : 1;
-  // Q pre-scaled into log2 units (scale = ln 2): the multiply-free softmax body
-  const bool unit = p.scale_log2e > 1.0f - 4e-7f && p.scale_log2e < 1.0f + 4e-7f;
+  const char* ve = getenv("LCV_ATTN_VAR");  // A/B knob: 0 register-staged K/V tiles, 1 LDS-DMA, 3 LDS-DMA + three-stage ping-pong
+  const int var = ve ? (ve[0] - '0') & 3 : 3;
   int rc;
   if (Nk <= 512) rc = launch(attn_fwd_kernel<NW, 0, true, 0>);
   else if (prio == 1) rc = launch(attn_fwd_kernel<NW, 1, false, 0>);
   else if (var == 0) rc = launch(attn_fwd_kernel<NW, 0, false, 0>);
-  else if (unit) rc = launch(attn_fwd_kernel<NW, 0, false, 3>);
-  else rc = launch(attn_fwd_kernel<NW, 0, false, 1>);
+  else if (var == 1 || var == 2) rc = launch(attn_fwd_kernel<NW, 0, false, 1>);
+  else rc = launch(attn_fwd_kernel<NW, 0, false, 3>);
   if (rc != LCV_OK) return rc;
   LCV_LAUNCH_CHECK("attn_fwd");
   return LCV_OK;

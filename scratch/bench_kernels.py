@@ -20,6 +20,20 @@ if which in ("all","attn"):
         ms=timeit(lambda: ops.attention(qkv[:,:,0],qkv[:,:,1],qkv[:,:,2],D**-0.5,out=o), n=3, warm=1)
         fl=4*N*N*H*D
         print(f"attn N={N}: {ms:.2f} ms  {fl/ms/1e9:.1f} TF/s", flush=True)
+if which in ("attn_unit",):
+    import math
+    for N in (46800,):
+        H=32; D=128
+        qkv=torch.randn(1,N,3,H,D,device=dev,dtype=torch.float32)
+        c=D**-0.5*math.log2(math.e)
+        q_pre=(qkv[:,:,0]*c).to(bf).contiguous(); qkv=qkv.to(bf)
+        o=torch.empty(1,N,H,D,device=dev,dtype=bf); o2=torch.empty_like(o)
+        ms=timeit(lambda: ops.attention(qkv[:,:,0],qkv[:,:,1],qkv[:,:,2],D**-0.5,out=o), n=3, warm=1)
+        fl=4*N*N*H*D
+        print(f"attn general N={N}: {ms:.2f} ms  {fl/ms/1e9:.1f} TF/s", flush=True)
+        ms=timeit(lambda: ops.attention(q_pre,qkv[:,:,1],qkv[:,:,2],math.log(2.0),out=o2), n=3, warm=1)
+        print(f"attn unit    N={N}: {ms:.2f} ms  {fl/ms/1e9:.1f} TF/s", flush=True)
+        d=(o.float()-o2.float()); print("rel_l2 unit vs general:", (d.norm()/o.float().norm()).item(), "max abs", d.abs().max().item())
 if which in ("all","gemm"):
     for (M,N,K,name) in ((46800,12288,4096,"qkv"),(46800,4096,4096,"proj"),(46800,22016,4096,"w13"),(46800,4096,11008,"w2")):
         a=torch.randn(M,K,device=dev,dtype=bf); w=torch.randn(N,K,device=dev,dtype=bf)*0.02; b=torch.randn(N,device=dev,dtype=bf)

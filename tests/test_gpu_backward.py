@@ -100,6 +100,12 @@ def test_qknorm_rope_backward():
         out = orc.apply_rope(orc.rmsnorm_fp32(src, w), ang)
         out.backward(dout.float().permute(0, 2, 1, 3))
         assert rel_l2(got.permute(0, 2, 1, 3), src.grad) < 5e-3, idx
+    # q_scale: the forward multiplied q by c, so dq_in scales by c; dk_in does not
+    c = ops.log2_qscale(D ** -0.5)
+    dqi2 = torch.empty_like(dqi); dki2 = torch.empty_like(dqi)
+    ops.qknorm_rope_bwd(d[:, :, 0], d[:, :, 1], dq.to(DEV), dk.to(DEV), dqi2, dki2, wq.to(DEV), wk.to(DEV), cs.to(DEV),
+                        q_scale=c)
+    assert rel_l2(dqi2, dqi.float() * c) < 5e-3 and torch.equal(dki2, dki)
 
 
 def test_linear_f32_backward_and_tn_skinny_and_unpatchify():

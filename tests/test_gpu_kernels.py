@@ -91,6 +91,15 @@ def test_qknorm_rope(grid, H):
         got = d[:, :, idx].permute(0, 2, 1, 3)
         assert rel_l2(got, ref) < 2e-3, idx
     assert torch.equal(d[:, :, 2].cpu(), qkv[:, :, 2])  # V untouched
+    # q_scale: the attention scale folded into q before ITS single bf16 rounding; k unaffected
+    c = ops.log2_qscale(D ** -0.5)
+    d2 = qkv.to(DEV)
+    ops.qknorm_rope(d2[:, :, 0], d2[:, :, 1], None, d2[:, :, 0], d2[:, :, 1], None, wq.to(DEV), wk.to(DEV), cs.to(DEV),
+                    q_scale=c)
+    src = qkv[:, :, 0].permute(0, 2, 1, 3)
+    ref = orc.bf16_round(orc.apply_rope(orc.rmsnorm_fp32(src, wq, rnd=orc.bf16_round), ang) * c)
+    assert rel_l2(d2[:, :, 0].permute(0, 2, 1, 3), ref) < 2e-3
+    assert torch.equal(d2[:, :, 1].cpu(), d[:, :, 1].cpu())
 
 
 @pytest.mark.parametrize("B,H,Nq,Nk", [(1, 2, 300, 300), (2, 1, 64, 77), (1, 1, 513, 1000), (1, 2, 256, 64), (1, 1, 31, 5)])
@@ -104,6 +113,23 @@ def test_attention(B, H, Nq, Nk):
     # tolerance: P is rounded to bf16 before PV (as flash-attn does) and O is stored in bf16
     assert rel_l2(o.permute(0, 2, 1, 3), ref) < 6e-3
     s = (q.permute(0, 2, 1, 3).float() @ k.permute(0, 2, 1, 3).float().transpose(-1, -2)) * scale
+    assert torch.allclose(lse.cpu(), torch.logsumexp(s, dim=-1), atol=2e-4, rtol=1e-5)
+
+
+@pytest.mark.parametrize("B,H,Nq,Nk", [(1, 2, 300, 300), (2, 1, 64, 77), (1, 1, 513, 1000), (1, 1, 31, 5), (1, 2, 700, 1664)])
+def test_attention_log2_prescaled_q(B, H, Nq, Nk):
+    """scale = ln 2 with q already multiplied by head_dim^-0.5 * log2(e): the multiply-free softmax body of the long-key
+    kernel (Nk > 512) and the general body (Nk <= 512) must both equal softmax(q'.k ln 2) v; one key row is spiked so the
+    running max jumps by more than the deferred-rescale threshold mid-stream, and 1000 / 77 / 5 are ragged last tiles."""
+    ops, orc = _ops(), _orc()
+    D = 128
+    c = ops.log2_qscale(D ** -0.5)
+    q = (_randn(B, Nq, H, D, seed=12).float() * c).to(BF16); k = _randn(B, Nk, H, D, seed=13); v = _randn(B, Nk, H, D, seed=14)
+    k[0, (2 * Nk) // 3] *= 6.0
+    o, lse = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), ops.LN2, need_lse=True)
+    ref = orc.sdpa(q.permute(0, 2, 1, 3), k.permute(0, 2, 1, 3), v.permute(0, 2, 1, 3), ops.LN2)
+    assert rel_l2(o.permute(0, 2, 1, 3), ref) < 6e-3
+    s = (q.permute(0, 2, 1, 3).float() @ k.permute(0, 2, 1, 3).float().transpose(-1, -2)) * ops.LN2
     assert torch.allclose(lse.cpu(), torch.logsumexp(s, dim=-1), atol=2e-4, rtol=1e-5)
 
 
