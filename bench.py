@@ -240,7 +240,7 @@ def main():
                    "depth": args.depth, "tokens": T * (h // 2) * (w // 2), "parallelism": f"{'sp' if sp else 'dp'}{world}",
                    "latent_frame_steps_per_s": T * (1 if sp else world) / sec_per_step,
                    "wall_clock_per_video_s_extrapolated": sec_per_step * args.num_inference_steps, **extras},
-        "roofline": {"kernel": "attn_fwd_kernel<8, 0, false, 1>", "bound": "mfma", "achieved": achieved, "peak": MFMA_PEAK_TFLOPS,
+        "roofline": {"kernel": "attn_fwd_kernel<8, 0, false, 3>", "bound": "mfma", "achieved": achieved, "peak": MFMA_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": traffic,
                      "avg_launch_ms": avg_ms, "launches": len(big), "flops_per_launch": flops},
     }

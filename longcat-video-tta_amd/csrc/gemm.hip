@@ -67,10 +67,9 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
 // of the tile sequence, and the sequence itself is "grouped": GROUP_M consecutive tile rows are walked column by column,
 // so the ~32 workgroups resident on one XCD cover an 8 x 4 block of tiles and share 8 A panels + 4 W panels in that
 // XCD's L2 instead of 32 A panels + 1 W panel.
-__device__ __forceinline__ void gemm_tile_coords(const GemmParams& p, int& tm, int& tn) {
+__device__ __forceinline__ void gemm_tile_coords(const GemmParams& p, int orig, int& tm, int& tn) {
   constexpr int GROUP_M = 8;
   const int nwg = p.tiles_m * p.tiles_n;
-  const int orig = blockIdx.x;
   const int xcd = orig & 7;
   const int q = nwg >> 3, r8 = nwg & 7;
   const int pid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (orig >> 3);
@@ -81,6 +80,9 @@ __device__ __forceinline__ void gemm_tile_coords(const GemmParams& p, int& tm, i
   const int in_group = pid - group * per_group;
   tm = first_m + in_group % gsz;
   tn = in_group / gsz;
+}
+__device__ __forceinline__ void gemm_tile_coords(const GemmParams& p, int& tm, int& tn) {
+  gemm_tile_coords(p, (int)blockIdx.x, tm, tn);
 }
 
 // ---- shared epilogue ----
@@ -571,19 +573,20 @@ __device__ __forceinline__ void wait_vmcnt() {
   else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
 }
 
-template <int EPI>
+// PERSIST: one workgroup per CU walks the tile sequence (virtual id = blockIdx.x + i * gridDim.x: gridDim.x is a multiple of 8,
+// so a workgroup keeps its XCD's run of the sequence), and the LDS-DMA prologue of the NEXT tile is issued before the
+// epilogue of the current one - the 128 KiB LDS image allows one workgroup per CU, so without this every tile exposes
+// its own pipeline fill and its store tail.
+template <int EPI, bool PERSIST>
 __global__ __launch_bounds__(512) void gemm8p_nt_kernel(const GemmParams p) {
   constexpr int BUF_BYTES = 65536, SLOT_BYTES = 16384;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  int tm, tn;
-  gemm_tile_coords(p, tm, tn);
-  const int64_t m0 = (int64_t)tm * 256;
-  const int64_t n0 = (int64_t)tn * 256;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
   const int r16 = lane & 15, q = lane >> 4;
+  const int nwg = p.tiles_m * p.tiles_n;
 
   // ---- LDS-DMA roles: instruction t of wave w fills slot rows 8 (2 w + t) .. +8; lane -> row (lane >> 3), 16-B position
   // (lane & 7) which holds logical chunk (lane & 7) ^ ((row >> 1) & 7).  Per-lane state is the (clamped) global row of
@@ -594,14 +597,27 @@ __global__ __launch_bounds__(512) void gemm8p_nt_kernel(const GemmParams p) {
   for (int t = 0; t < 2; ++t) {
     const int srow = 8 * (2 * wave + t) + (lane >> 3);
     swz[t] = (unsigned)(((lane & 7) ^ ((srow >> 1) & 7)) * 16);
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      int64_t g = m0 + (srow >> 6) * 128 + h * 64 + (srow & 63);
-      arow[h][t] = (int)(g > p.M - 1 ? p.M - 1 : g);
-      g = n0 + (srow >> 5) * 64 + h * 32 + (srow & 31);
-      wrow[h][t] = (int)(g > p.N - 1 ? p.N - 1 : g);
-    }
   }
+  int64_t m0 = 0, n0 = 0;
+  auto setup_tile = [&](int vid) {
+    int tm, tn;
+    gemm_tile_coords(p, vid, tm, tn);
+    m0 = (int64_t)tm * 256;
+    n0 = (int64_t)tn * 256;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int srow = 8 * (2 * wave + t) + (lane >> 3);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        int64_t g = m0 + (srow >> 6) * 128 + h * 64 + (srow & 63);
+        arow[h][t] = (int)(g > p.M - 1 ? p.M - 1 : g);
+        g = n0 + (srow >> 5) * 64 + h * 32 + (srow & 31);
+        wrow[h][t] = (int)(g > p.N - 1 ? p.N - 1 : g);
+      }
+    }
+  };
+  int vid = blockIdx.x;
+  setup_tile(vid);
   auto stage_a = [&](auto mq_c, int kts, int buf) {
     constexpr int mq = decltype(mq_c)::value;
     const bool lora = kts >= p.nk1;  // the rank-r pair (a2, w2) supplies the last nk2 K tiles
@@ -708,52 +724,79 @@ __global__ __launch_bounds__(512) void gemm8p_nt_kernel(const GemmParams p) {
 
   // ---- prologue: the steady-state issue order A-mq0, W-nq0, W-nq1, A-mq1 of tile 0, then A-mq0, W-nq0 of tile 1 ----
   const int nk = p.nk1 + p.nk2;  // >= 2, nk1 >= 2 (host-checked)
-  stage_a(C0{}, 0, 0);
-  stage_w(C0{}, 0, 0);
-  stage_w(C1{}, 0, 0);
-  stage_a(C1{}, 0, 0);
-  stage_a(C0{}, 1, 1);
-  stage_w(C0{}, 1, 1);
-  wait_vmcnt<8>();  // A-mq0 and W-nq0 of tile 0 have landed
-  __builtin_amdgcn_s_barrier();
-  if (wr == 1) __builtin_amdgcn_s_barrier();  // the lower wave row runs one barrier behind
+  auto prologue = [&]() {
+    stage_a(C0{}, 0, 0);
+    stage_w(C0{}, 0, 0);
+    stage_w(C1{}, 0, 0);
+    stage_a(C1{}, 0, 0);
+    stage_a(C0{}, 1, 1);
+    stage_w(C0{}, 1, 1);
+  };
+  prologue();
+  for (;;) {
+    // A-mq0 and W-nq0 of K tile 0 have landed (persistent: the previous tile's stores are younger than the prologue, so
+    // this also retires the whole prologue and all but 8 of those stores - conservative, never early)
+    wait_vmcnt<8>();
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();  // the lower wave row runs one barrier behind
 
-  int kt = 0;
-  for (; kt < nk - 2; ++kt) {
-    const int buf = kt & 1;
-    phase(P1{}, C1{}, V8{}, kt, buf);
-    phase(P2{}, C1{}, V8{}, kt, buf);
-    phase(P3{}, C1{}, V8{}, kt, buf);
-    phase(P4{}, C1{}, V8{}, kt, buf);
-    flip();
-  }
-  {  // K tile nk-2: nothing left to stage for tile nk
-    const int buf = kt & 1;
-    phase(P1{}, C1{}, V8{}, kt, buf);
-    phase(P2{}, C1{}, V8{}, kt, buf);
-    phase(P3{}, C0{}, V6{}, kt, buf);
-    phase(P4{}, C0{}, V4{}, kt, buf);
-    flip();
-    ++kt;
-  }
-  {  // K tile nk-1
-    const int buf = kt & 1;
-    phase(P1{}, C0{}, V2{}, kt, buf);
-    phase(P2{}, C0{}, V0{}, kt, buf);
-    phase(P3{}, C0{}, VN{}, kt, buf);
-    phase(P4{}, C0{}, VN{}, kt, buf);
-  }
-  if (wr == 0) __builtin_amdgcn_s_barrier();  // balance the stagger
+    int kt = 0;
+    for (; kt < nk - 2; ++kt) {
+      const int buf = kt & 1;
+      phase(P1{}, C1{}, V8{}, kt, buf);
+      phase(P2{}, C1{}, V8{}, kt, buf);
+      phase(P3{}, C1{}, V8{}, kt, buf);
+      phase(P4{}, C1{}, V8{}, kt, buf);
+      flip();
+    }
+    {  // K tile nk-2: nothing left to stage for tile nk
+      const int buf = kt & 1;
+      phase(P1{}, C1{}, V8{}, kt, buf);
+      phase(P2{}, C1{}, V8{}, kt, buf);
+      phase(P3{}, C0{}, V6{}, kt, buf);
+      phase(P4{}, C0{}, V4{}, kt, buf);
+      flip();
+      ++kt;
+    }
+    {  // K tile nk-1
+      const int buf = kt & 1;
+      phase(P1{}, C0{}, V2{}, kt, buf);
+      phase(P2{}, C0{}, V0{}, kt, buf);
+      phase(P3{}, C0{}, VN{}, kt, buf);
+      phase(P4{}, C0{}, VN{}, kt, buf);
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();  // balance the stagger
 
-  gemm16_epilogue<8, 4, EPI>(p, acc, m0 + wr * 128, n0 + wc * 64, r16, q);
+    const int64_t mw = m0 + wr * 128, nw = n0 + wc * 64;
+    if constexpr (PERSIST) {
+      // every wave is past its last LDS read: both buffers are free, so the next tile's pipeline fills under this epilogue
+      const int next = vid + (int)gridDim.x;
+      const bool more = next < nwg;
+      if (more) {
+        if (kt & 1) flip();  // fragment read bases back to buffer 0
+        setup_tile(next);
+        prologue();
+      }
+      gemm16_epilogue<8, 4, EPI>(p, acc, mw, nw, r16, q);
+      if (!more) break;
+      vid = next;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    } else {
+      gemm16_epilogue<8, 4, EPI>(p, acc, mw, nw, r16, q);
+      break;
+    }
+  }
 }
 
-template <int EPI>
+template <int EPI, bool PERSIST>
 static int launch_gemm8p(GemmParams& p, hipStream_t s) {
   p.tiles_m = (int)((p.M + 255) / 256);
   p.tiles_n = (int)((p.N + 255) / 256);
   const size_t lds = 2 * 65536;
-  auto kern = gemm8p_nt_kernel<EPI>;
+  auto kern = gemm8p_nt_kernel<EPI, PERSIST>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
@@ -762,7 +805,9 @@ static int launch_gemm8p(GemmParams& p, hipStream_t s) {
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), lds, s, p);
+  unsigned grid = (unsigned)(p.tiles_m * p.tiles_n);
+  if (PERSIST && grid > 256) grid = 256;  // one workgroup per CU (the LDS image allows no more); a multiple of 8 XCDs
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, p);
   LCV_LAUNCH_CHECK("gemm8p_nt");
   return LCV_OK;
 }
@@ -817,10 +862,11 @@ static int dispatch_tile(GemmParams& p, hipStream_t s) {
   // 8-phase ping-pong schedule on the same tile; its LDS-DMA sources are 32-bit byte offsets from the operand base
   const bool ok8 = p.nk1 >= 2 && (uint64_t)p.M * p.lda * 2 < (1ull << 32) && (uint64_t)p.N * p.ldw * 2 < (1ull << 32) &&
                    (p.nk2 == 0 || ((uint64_t)p.M * p.lda2 * 2 < (1ull << 32) && (uint64_t)p.N * p.ldw2 * 2 < (1ull << 32)));
-  if (mode == 6 && ok8) mode = 8;
+  if (mode == 6 && ok8) mode = 9;  // persistent workgroups (identical to 8 when there are no more tiles than CUs)
   if (force) mode = force[0] - '0';
-  if (mode == 8 && ok8) return launch_gemm8p<EPI>(p, s);
-  if (mode == 6 || mode == 8) return launch_gemm16<256, 256, 2, 4, EPI, false>(p, s);
+  if (mode == 8 && ok8) return launch_gemm8p<EPI, false>(p, s);
+  if (mode == 9 && ok8) return launch_gemm8p<EPI, true>(p, s);
+  if (mode == 6 || mode == 8 || mode == 9) return launch_gemm16<256, 256, 2, 4, EPI, false>(p, s);
   if (mode == 7) return launch_gemm16<128, 128, 2, 2, EPI, false>(p, s);
   if (mode == 2) return launch_gemm<256, 256, 2, 4, EPI, false>(p, s);
   return launch_gemm<128, 128, 2, 2, EPI, false>(p, s);

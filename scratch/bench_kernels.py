@@ -37,7 +37,7 @@ if which in ("attn_unit",):
 if which in ("all","gemm"):
     for (M,N,K,name) in ((46800,12288,4096,"qkv"),(46800,4096,4096,"proj"),(46800,22016,4096,"w13"),(46800,4096,11008,"w2")):
         a=torch.randn(M,K,device=dev,dtype=bf); w=torch.randn(N,K,device=dev,dtype=bf)*0.02; b=torch.randn(N,device=dev,dtype=bf)
-        for tile in ("6","8"):
+        for tile in ("8","9"):
             os.environ["LCV_GEMM_TILE"]=tile
             ms=timeit(lambda: ops.gemm_nt(a,w,b), n=5, warm=2)
             print(f"gemm[{tile}] {name} M={M} N={N} K={K}: {ms:.2f} ms  {2*M*N*K/ms/1e9:.1f} TF/s", flush=True)

@@ -146,7 +146,8 @@ def test_attention_strided_packed_qkv_and_spike():
 
 
 @pytest.mark.parametrize("M,N,K,tile", [(300, 192, 128, "1"), (70, 64, 64, "1"), (2050, 1024, 256, "2"), (513, 768, 192, "2"), (700, 300, 1088, "2"), (2050, 1024, 256, "6"), (513, 768, 192, "6"), (700, 300, 1088, "6"), (300, 192, 128, "7"), (70, 64, 64, "7"),
-                                          (2050, 1024, 256, "8"), (513, 768, 192, "8"), (700, 300, 1088, "8"), (300, 192, 128, "8")])
+                                          (2050, 1024, 256, "8"), (513, 768, 192, "8"), (700, 300, 1088, "8"), (300, 192, 128, "8"),
+                                          (2050, 1024, 256, "9"), (513, 768, 192, "9"), (300, 192, 128, "9")])
 def test_gemm_nt_bias(M, N, K, tile, monkeypatch):
     monkeypatch.setenv("LCV_GEMM_TILE", tile)
     ops, orc = _ops(), _orc()
@@ -158,7 +159,7 @@ def test_gemm_nt_bias(M, N, K, tile, monkeypatch):
     assert rel_l2(c32, orc.linear(a, w, b)) < 1e-5
 
 
-@pytest.mark.parametrize("tile", ["1", "7", "8"])
+@pytest.mark.parametrize("tile", ["1", "7", "8", "9"])
 def test_gemm_nt_lora_and_epilogues(tile, monkeypatch):
     monkeypatch.setenv("LCV_GEMM_TILE", tile)
     ops, orc = _ops(), _orc()
@@ -205,16 +206,31 @@ def test_gemm_8phase_matches_plain_schedule_bitwise(monkeypatch):
     a = _randn(M, K, seed=61).to(DEV); w = _randn(N, K, seed=62, scale=0.05).to(DEV); b = _randn(N, seed=63).to(DEV)
     monkeypatch.setenv("LCV_GEMM_TILE", "6")
     ref = ops.gemm_nt(a, w, b)
-    monkeypatch.setenv("LCV_GEMM_TILE", "8")
-    for _ in range(5):
-        assert torch.equal(ops.gemm_nt(a, w, b), ref)
+    for tile in ("8", "9"):  # 9 = persistent workgroups (here 17 x 9 = 153 tiles on <= 256 CUs, see the next test for > 256)
+        monkeypatch.setenv("LCV_GEMM_TILE", tile)
+        for _ in range(5):
+            assert torch.equal(ops.gemm_nt(a, w, b), ref)
     # with the rank-r pair as the last K tile
     a2 = _randn(M, 64, seed=64).to(DEV); w2 = _randn(N, 64, seed=65, scale=0.05).to(DEV)
     monkeypatch.setenv("LCV_GEMM_TILE", "6")
     ref = ops.gemm_nt(a, w, b, a2=a2, w2=w2)
-    monkeypatch.setenv("LCV_GEMM_TILE", "8")
-    for _ in range(3):
-        assert torch.equal(ops.gemm_nt(a, w, b, a2=a2, w2=w2), ref)
+    for tile in ("8", "9"):
+        monkeypatch.setenv("LCV_GEMM_TILE", tile)
+        for _ in range(3):
+            assert torch.equal(ops.gemm_nt(a, w, b, a2=a2, w2=w2), ref)
+
+
+def test_gemm_persistent_many_tiles_bitwise(monkeypatch):
+    """More tiles than CUs, so every persistent workgroup walks several tiles and each tile's LDS-DMA prologue is issued
+    under the previous tile's epilogue; ragged M and N edges; must equal the one-barrier kernel bit for bit."""
+    ops = _ops()
+    M, N, K = 256 * 37 + 19, 256 * 11 + 40, 512
+    a = _randn(M, K, seed=71).to(DEV); w = _randn(N, K, seed=72, scale=0.05).to(DEV); b = _randn(N, seed=73).to(DEV)
+    monkeypatch.setenv("LCV_GEMM_TILE", "6")
+    ref = ops.gemm_nt(a, w, b)
+    monkeypatch.setenv("LCV_GEMM_TILE", "9")
+    for _ in range(4):
+        assert torch.equal(ops.gemm_nt(a, w, b), ref)
 
 
 def test_linear_f32_smallm():
