@@ -249,7 +249,7 @@ int lcv_adamw_step(const lcv_adam_tensor* tensors, int64_t n_tensors, int64_t to
                    const float* norm_coef, double lr, double beta1, double beta2, double eps, double weight_decay,
                    int64_t step, void* stream);
 
-/* ---- VAE decoder stages (WAN-style causal 3-D conv VAE; upstream AutoencoderKLWan.decode, contract at
+/* ---- VAE stages (WAN-style causal 3-D conv VAE; upstream AutoencoderKLWan.decode / .encode, contract at
  * delta_experiment/scripts/common.py:209-221) --------------------------------------------------------------- */
 /* Causal conv3d as an implicit GEMM on the MFMA core.  x [B,Tin,Hin,Win,Cin] channels-last bf16 (Cin % 64 == 0,
  * padded channels zero); w [Cout, kt*kh*kw*Cin] with K ordered (dt,dh,dw,cin); out [B,T,H,W,ldc], (H,W) doubled when
@@ -258,6 +258,13 @@ int lcv_adamw_step(const lcv_adam_tensor* tensors, int64_t n_tensors, int64_t to
 int lcv_causal_conv3d(const void* x, const void* w, const void* bias, const void* resid, void* out,
                       const void* zero_page, int64_t B, int64_t Tin, int64_t Hin, int64_t Win, int64_t Cin,
                       int64_t Cout, int64_t ldc, int kt, int kh, int kw, int up2x, void* stream);
+/* Strided conv3d for the VAE ENCODER's downsampling stages (upstream WanResample "downsample2d/3d": ZeroPad2d((0,1,0,1))
+ * + 3x3 stride-2 conv per frame; (3,1,1) stride-2 temporal conv over [cached last frame | chunk]; contract of
+ * vae.encode at delta_experiment/scripts/common.py:158-174).  Output pixel (t,h,w) reads input (t*st+dt, h*sh+dh, w*sw+dw),
+ * no front padding, taps past the input extent read zeros; the caller gives the output extent. */
+int lcv_conv3d_strided(const void* x, const void* w, const void* bias, void* out, const void* zero_page, int64_t B,
+                       int64_t Tin, int64_t Hin, int64_t Win, int64_t Cin, int64_t Cout, int64_t ldc, int kt, int kh,
+                       int kw, int st, int sh, int sw, int64_t Tout, int64_t Hout, int64_t Wout, void* stream);
 /* WAN RMS_norm over channels (channels-last rows padded to Cpad): y = x / max(||x||_2, 1e-12) * sqrt(C) * gamma,
  * optional SiLU; padding channels are written as zeros. */
 int lcv_vae_rmsnorm_silu(const void* x, const void* gamma, void* y, int64_t rows, int64_t C, int64_t Cpad,

@@ -41,6 +41,8 @@ struct GemmParams {
   int cv_Tin, cv_Hin, cv_Win;  // input extent
   int cv_kt, cv_kh, cv_kw, cv_cpt;  // taps and 64-channel chunks per tap (Cin / 64)
   int cv_up2x;                 // nearest 2x spatial upsample folded into the gather
+  int cv_st, cv_sh, cv_sw;     // output -> input strides (downsampling convs of the VAE encoder)
+  int cv_pt, cv_ph, cv_pw;     // zero padding IN FRONT of each axis (causal: kt-1 frames; "same": k/2; encoder downsample: 0)
   const bf16_t* cv_zero;       // >= 128 bytes of zeros
 };
 
@@ -259,10 +261,11 @@ __global__ __launch_bounds__(WR* WC * 64) void gemm_nt_kernel(const GemmParams p
       const int dt = tap / (p.cv_kw * p.cv_kh);
 #pragma unroll
       for (int t = 0; t < Cfg::IA; ++t) {
-        const int ti = cv_t[t] + dt - (p.cv_kt - 1);      // causal: kt-1 frames of zero padding in front
-        int hi = cv_h[t] + dh - (p.cv_kh >> 1);
-        int wi = cv_w[t] + dw - (p.cv_kw >> 1);
-        const bool ok = ti >= 0 && hi >= 0 && hi < p.cv_H && wi >= 0 && wi < p.cv_W;
+        const int ti = cv_t[t] * p.cv_st + dt - p.cv_pt;  // front padding only: causal in t, (k/2 | 0) in h, w
+        int hi = cv_h[t] * p.cv_sh + dh - p.cv_ph;
+        int wi = cv_w[t] * p.cv_sw + dw - p.cv_pw;
+        const int hb = p.cv_up2x ? 2 * p.cv_Hin : p.cv_Hin, wb = p.cv_up2x ? 2 * p.cv_Win : p.cv_Win;
+        const bool ok = ti >= 0 && ti < p.cv_Tin && hi >= 0 && hi < hb && wi >= 0 && wi < wb;
         if (p.cv_up2x) { hi >>= 1; wi >>= 1; }
         const int64_t pix = ((a_row[t] * p.cv_Tin + ti) * p.cv_Hin + hi) * (int64_t)p.cv_Win + wi;
         const bf16_t* src = ok ? (A + pix * lda + c0 + a_sw[t]) : (p.cv_zero + a_sw[t]);
@@ -486,10 +489,11 @@ __global__ __launch_bounds__(WR* WC * 64) void gemm16_nt_kernel(const GemmParams
       const int dt = tap / (p.cv_kw * p.cv_kh);
 #pragma unroll
       for (int t = 0; t < Cfg::IA; ++t) {
-        const int ti = cv_t[t] + dt - (p.cv_kt - 1);
-        int hi = cv_h[t] + dh - (p.cv_kh >> 1);
-        int wi = cv_w[t] + dw - (p.cv_kw >> 1);
-        const bool ok = ti >= 0 && hi >= 0 && hi < p.cv_H && wi >= 0 && wi < p.cv_W;
+        const int ti = cv_t[t] * p.cv_st + dt - p.cv_pt;  // front padding only: causal in t, (k/2 | 0) in h, w
+        int hi = cv_h[t] * p.cv_sh + dh - p.cv_ph;
+        int wi = cv_w[t] * p.cv_sw + dw - p.cv_pw;
+        const int hb = p.cv_up2x ? 2 * p.cv_Hin : p.cv_Hin, wb = p.cv_up2x ? 2 * p.cv_Win : p.cv_Win;
+        const bool ok = ti >= 0 && ti < p.cv_Tin && hi >= 0 && hi < hb && wi >= 0 && wi < wb;
         if (p.cv_up2x) { hi >>= 1; wi >>= 1; }
         const int64_t pix = ((a_row[t] * p.cv_Tin + ti) * p.cv_Hin + hi) * (int64_t)p.cv_Win + wi;
         const bf16_t* src = ok ? (A + pix * lda + c0 + a_sw[t]) : (p.cv_zero + a_sw[t]);
@@ -899,6 +903,7 @@ extern "C" int lcv_gemm_nt(const void* a, const void* w, const void* bias, const
   p.resid = (const bf16_t*)resid; p.gate = mod ? mod + gate_off : nullptr;
   p.rows_per_frame = rows_per_frame > 0 ? rows_per_frame : 1; p.mod_stride = mod_stride;
   p.cv_zero = nullptr; p.cv_up2x = 0; p.cv_cpt = 1;
+  p.cv_st = p.cv_sh = p.cv_sw = 1; p.cv_pt = p.cv_ph = p.cv_pw = 0;
   hipStream_t s = (hipStream_t)stream;
   switch (epilogue) {
     case LCV_EPI_NONE: return dispatch_tile<LCV_EPI_NONE>(p, s);
@@ -924,20 +929,17 @@ extern "C" int lcv_gemm_nt(const void* a, const void* w, const void* bias, const
 // Temporal padding is causal (kt-1 zero frames in front), spatial padding kh/2, kw/2 zeros.
 // resid (nullable, same layout as out): out = resid + bf16(conv + bias)  (residual-block tail).
 // ---------------------------------------------------------------------------
-extern "C" int lcv_causal_conv3d(const void* x, const void* w, const void* bias, const void* resid, void* out,
-                                 const void* zero_page, int64_t B, int64_t Tin, int64_t Hin, int64_t Win,
-                                 int64_t Cin, int64_t Cout, int64_t ldc, int kt, int kh, int kw, int up2x,
-                                 void* stream) {
-  LCV_CHECK_ARG(x && w && out && zero_page, "causal_conv3d: null pointer");
-  LCV_CHECK_ARG(Cin > 0 && Cin % 64 == 0, "causal_conv3d: Cin=%ld must be a multiple of 64 (pad channels)", (long)Cin);
-  LCV_CHECK_ARG(kt >= 1 && kh >= 1 && kw >= 1 && (kh & 1) && (kw & 1), "causal_conv3d: odd spatial kernels only");
-  LCV_CHECK_ARG(ldc >= Cout, "causal_conv3d: ldc < Cout");
+static int conv3d_impl(const void* x, const void* w, const void* bias, const void* resid, void* out, const void* zero_page,
+                       int64_t B, int64_t Tin, int64_t Hin, int64_t Win, int64_t Cin, int64_t Cout, int64_t ldc, int kt, int kh,
+                       int kw, int up2x, int st, int sh, int sw, int pt, int ph, int pw, int64_t Tout, int64_t Hout,
+                       int64_t Wout, void* stream) {
   GemmParams p;
   p.a = (const bf16_t*)x; p.w = (const bf16_t*)w; p.bias = (const bf16_t*)bias; p.a2 = nullptr; p.w2 = nullptr;
   p.c = out;
-  p.cv_T = (int)Tin; p.cv_H = (int)(up2x ? 2 * Hin : Hin); p.cv_W = (int)(up2x ? 2 * Win : Win);
+  p.cv_T = (int)Tout; p.cv_H = (int)Hout; p.cv_W = (int)Wout;
   p.cv_Tin = (int)Tin; p.cv_Hin = (int)Hin; p.cv_Win = (int)Win;
   p.cv_kt = kt; p.cv_kh = kh; p.cv_kw = kw; p.cv_cpt = (int)(Cin / 64); p.cv_up2x = up2x;
+  p.cv_st = st; p.cv_sh = sh; p.cv_sw = sw; p.cv_pt = pt; p.cv_ph = ph; p.cv_pw = pw;
   p.cv_zero = (const bf16_t*)zero_page;
   p.M = B * p.cv_T * (int64_t)p.cv_H * p.cv_W; p.N = Cout;
   p.nk1 = kt * kh * kw * p.cv_cpt; p.nk2 = 0;
@@ -947,6 +949,36 @@ extern "C" int lcv_causal_conv3d(const void* x, const void* w, const void* bias,
   hipStream_t s = (hipStream_t)stream;
   if (resid) return dispatch_conv<LCV_EPI_GATE_RESIDUAL>(p, s);
   return dispatch_conv<LCV_EPI_NONE>(p, s);
+}
+
+extern "C" int lcv_causal_conv3d(const void* x, const void* w, const void* bias, const void* resid, void* out,
+                                 const void* zero_page, int64_t B, int64_t Tin, int64_t Hin, int64_t Win,
+                                 int64_t Cin, int64_t Cout, int64_t ldc, int kt, int kh, int kw, int up2x,
+                                 void* stream) {
+  LCV_CHECK_ARG(x && w && out && zero_page, "causal_conv3d: null pointer");
+  LCV_CHECK_ARG(Cin > 0 && Cin % 64 == 0, "causal_conv3d: Cin=%ld must be a multiple of 64 (pad channels)", (long)Cin);
+  LCV_CHECK_ARG(kt >= 1 && kh >= 1 && kw >= 1 && (kh & 1) && (kw & 1), "causal_conv3d: odd spatial kernels only");
+  LCV_CHECK_ARG(ldc >= Cout, "causal_conv3d: ldc < Cout");
+  return conv3d_impl(x, w, bias, resid, out, zero_page, B, Tin, Hin, Win, Cin, Cout, ldc, kt, kh, kw, up2x, 1, 1, 1, kt - 1,
+                     kh >> 1, kw >> 1, Tin, up2x ? 2 * Hin : Hin, up2x ? 2 * Win : Win, stream);
+}
+
+// Strided form for the VAE encoder's downsampling convolutions: output pixel (t, h, w) reads input
+// (t*st + dt, h*sh + dh, w*sw + dw) for dt < kt, dh < kh, dw < kw - NO front padding; taps past the input extent read
+// zeros (that is the reference's ZeroPad2d((0,1,0,1)) + stride-2 3x3 conv, and its (3,1,1) stride-2 temporal conv over
+// [last cached frame | chunk]).  The caller gives the output extent.
+extern "C" int lcv_conv3d_strided(const void* x, const void* w, const void* bias, void* out, const void* zero_page,
+                                  int64_t B, int64_t Tin, int64_t Hin, int64_t Win, int64_t Cin, int64_t Cout,
+                                  int64_t ldc, int kt, int kh, int kw, int st, int sh, int sw, int64_t Tout,
+                                  int64_t Hout, int64_t Wout, void* stream) {
+  LCV_CHECK_ARG(x && w && out && zero_page, "conv3d_strided: null pointer");
+  LCV_CHECK_ARG(Cin > 0 && Cin % 64 == 0, "conv3d_strided: Cin=%ld must be a multiple of 64 (pad channels)", (long)Cin);
+  LCV_CHECK_ARG(kt >= 1 && kh >= 1 && kw >= 1 && st >= 1 && sh >= 1 && sw >= 1, "conv3d_strided: bad kernel / stride");
+  LCV_CHECK_ARG(ldc >= Cout, "conv3d_strided: ldc < Cout");
+  LCV_CHECK_ARG(Tout >= 0 && Hout >= 0 && Wout >= 0 && (Tout - 1) * st < Tin && (Hout - 1) * sh < Hin && (Wout - 1) * sw < Win,
+                "conv3d_strided: output extent reaches past the input");
+  return conv3d_impl(x, w, bias, nullptr, out, zero_page, B, Tin, Hin, Win, Cin, Cout, ldc, kt, kh, kw, 0, st, sh, sw, 0, 0, 0,
+                     Tout, Hout, Wout, stream);
 }
 
 // ---------------------------------------------------------------------------

@@ -42,6 +42,7 @@ _SIGNATURES = {
     "lcv_grad_norm_clip": [P, I64, I64, I, F32, P, P, P],
     "lcv_adamw_step": [P, I64, I64, I, P, F64, F64, F64, F64, F64, I64, P],
     "lcv_causal_conv3d": [P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I, I, I, I, P],
+    "lcv_conv3d_strided": [P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I, I, I, I, I, I, I64, I64, I64, P],
     "lcv_vae_rmsnorm_silu": [P, P, P, I64, I64, I64, I, P],
     "lcv_softmax_rows": [P, P, I64, I64, I64, I64, F32, P],
 }

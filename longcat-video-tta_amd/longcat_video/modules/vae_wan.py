@@ -1,8 +1,10 @@
-"""WAN-style causal 3-D VAE decoder on the gfx950 kernels (whole sequence at once, channels-last).
+"""WAN-style causal 3-D VAE (decoder and encoder) on the gfx950 kernels (whole sequence at once, channels-last).
 
 Contract kept for the reference (delta_experiment/scripts/common.py:65-67, 158-221): `AutoencoderKLWan.from_pretrained(dir,
 subfolder="vae", torch_dtype=)`, `.config.{z_dim, latents_mean, latents_std}`, `.dtype`, `.decode(z, return_dict=False)[0]`
--> `[B, 3, 1+4(T-1), 8h, 8w]` in [-1, 1].  Parameter names follow the diffusers module tree (`decoder.conv_in`,
+-> `[B, 3, 1+4(T-1), 8h, 8w]` in [-1, 1], `.encode(video).latent_dist.{mode(), sample(generator)}` with video
+`[B, 3, 1+4k, 8h, 8w]` in [-1, 1] -> `[B, z_dim, 1+k, h, w]` (common.py:158-174; pipeline `generate_vc` encodes the
+conditioning frames with it).  Parameter names follow the diffusers module tree (`decoder.conv_in`,
 `decoder.mid_block.resnets.0.norm1.gamma`, `decoder.up_blocks.i.upsamplers.0.{resample.1,time_conv}`, `post_quant_conv`)
 so a published checkpoint loads by name.  [assumed-from-upstream] graph: see oracle/vae_oracle.py header.
 
@@ -109,6 +111,54 @@ class _Resample(nn.Module):
             self.time_conv = _Conv(dim, 2 * dim, (3, 1, 1), **kw)
 
 
+class _DownResample(nn.Module):
+    """upstream WanResample("downsample2d" | "downsample3d"): ZeroPad2d((0,1,0,1)) + 3x3 stride-2 conv per frame, then for 3d a
+    (3,1,1) stride-2 temporal conv from which the first frame is exempt."""
+
+    def __init__(self, dim, mode, **kw):
+        super().__init__()
+        self.mode = mode
+        self.resample = nn.ModuleList([nn.Identity(), _Conv(dim, dim, (3, 3), **kw)])
+        if mode == "downsample3d":
+            self.time_conv = _Conv(dim, dim, (3, 1, 1), **kw)
+
+
+class _Encoder(nn.Module):
+    def __init__(self, dim, z_dim, dim_mult, num_res_blocks, temperal_downsample, **kw):
+        super().__init__()
+        dims = [dim * u for u in [1] + dim_mult]
+        self.conv_in = _Conv(3, dims[0], (3, 3, 3), **kw)
+        blocks = []
+        for i, (ci, co) in enumerate(zip(dims[:-1], dims[1:])):
+            for _ in range(num_res_blocks):
+                blocks.append(_Res(ci, co, **kw))
+                ci = co
+            if i != len(dim_mult) - 1:
+                blocks.append(_DownResample(co, "downsample3d" if temperal_downsample[i] else "downsample2d", **kw))
+        self.down_blocks = nn.ModuleList(blocks)   # flat, as upstream names them
+        self.mid_block = _Mid(dims[-1], **kw)
+        self.norm_out = _Norm(dims[-1], **kw)
+        self.conv_out = _Conv(dims[-1], 2 * z_dim, (3, 3, 3), **kw)
+
+
+class DiagonalGaussianDistribution:
+    """The posterior object the reference reads (`retrieve_latents`: `.mode()`; `.sample(generator)` kept for parity of the
+    surface): parameters [B, 2 z, T, h, w] = (mean | logvar), logvar clamped to [-30, 20]."""
+
+    def __init__(self, parameters: torch.Tensor):
+        self.parameters = parameters
+        self.mean, logvar = torch.chunk(parameters, 2, dim=1)
+        self.logvar = torch.clamp(logvar, -30.0, 20.0)
+        self.std = torch.exp(0.5 * self.logvar)
+
+    def mode(self) -> torch.Tensor:
+        return self.mean
+
+    def sample(self, generator=None) -> torch.Tensor:
+        eps = torch.randn(self.mean.shape, generator=generator, device=self.mean.device, dtype=self.mean.dtype)
+        return self.mean + self.std * eps
+
+
 class _UpBlock(nn.Module):
     def __init__(self, ci, co, n_res, mode, **kw):
         super().__init__()
@@ -151,6 +201,9 @@ class AutoencoderKLWan(nn.Module):
         kw = dict(device=device, dtype=dtype)
         self.post_quant_conv = _Conv(z_dim, z_dim, (1, 1, 1), **kw)
         self.decoder = _Decoder(base_dim, z_dim, list(dim_mult), num_res_blocks, list(temperal_downsample)[::-1], **kw)
+        self.quant_conv = _Conv(2 * z_dim, 2 * z_dim, (1, 1, 1), **kw)
+        self.encoder = _Encoder(base_dim, z_dim, list(dim_mult), num_res_blocks, list(temperal_downsample), **kw)
+        self._has_encoder = True
         self._zero = None
 
     @property
@@ -167,10 +220,12 @@ class AutoencoderKLWan(nn.Module):
         state = {}
         for s in sorted(x for x in os.listdir(path) if x.endswith(".safetensors")):
             state.update(load_file(os.path.join(path, s)))
-        dec = {k: v for k, v in state.items() if k.startswith(("decoder.", "post_quant_conv."))}
-        missing, _ = m.load_state_dict(dec, strict=False)
-        if missing:
-            raise RuntimeError(f"VAE checkpoint is missing {len(missing)} decoder tensors, e.g. {missing[:5]}")
+        keep = {k: v for k, v in state.items() if k.startswith(("decoder.", "post_quant_conv.", "encoder.", "quant_conv."))}
+        missing, _ = m.load_state_dict(keep, strict=False)
+        dec_missing = [k for k in missing if k.startswith(("decoder.", "post_quant_conv."))]
+        if dec_missing:
+            raise RuntimeError(f"VAE checkpoint is missing {len(dec_missing)} decoder tensors, e.g. {dec_missing[:5]}")
+        m._has_encoder = not any(k.startswith(("encoder.", "quant_conv.")) for k in missing)  # decoder-only checkpoints load
         return m
 
     @torch.no_grad()
@@ -186,10 +241,6 @@ class AutoencoderKLWan(nn.Module):
                 fan = p[0].numel()
                 p.copy_(torch.randn(p.shape, generator=g, device=dev, dtype=torch.float32) * fan ** -0.5)
         return self
-
-    def encode(self, x):
-        raise NotImplementedError("the VAE encoder is the next row after the hot path (SURVEY §8(f) rank 1); "
-                                  "this round decodes only")
 
     # ------------------------------------------------------------------ kernels
     def _zero_page(self, dev):
@@ -253,6 +304,59 @@ class AutoencoderKLWan(nn.Module):
                 parts.append(torch.cat([x[b:b + 1, :1], y], dim=1))
             x = torch.cat(parts, dim=0) if B > 1 else parts[0]
         return self._conv(x.contiguous(), u.resample[1], up2x=True)
+
+    def _conv_strided(self, x, conv: _Conv, stride, out_thw):
+        """x [B,T,H,W,Cpad] -> [B,T',H',W',pad64(Cout)], no front padding, zero taps past the input (lcv_conv3d_strided)."""
+        B, T, H, W, Cp = x.shape
+        k = conv.k if len(conv.k) == 3 else (1,) + conv.k
+        To, Ho, Wo = out_thw
+        ldc = _pad64(conv.cout)
+        alloc = torch.zeros if ldc != conv.cout else torch.empty
+        out = alloc((B, To, Ho, Wo, ldc), dtype=BF16, device=x.device)
+        call("lcv_conv3d_strided", x.data_ptr(), conv.packed().data_ptr(), conv.bias.data_ptr(), out.data_ptr(),
+             self._zero_page(x.device).data_ptr(), B, T, H, W, Cp, conv.cout, ldc, k[0], k[1], k[2], stride[0], stride[1],
+             stride[2], To, Ho, Wo, ops._stream())
+        return out
+
+    def _downsample(self, x, d: "_DownResample"):
+        B, T, H, W, C = x.shape
+        x = self._conv_strided(x, d.resample[1], (1, 2, 2), (T, H // 2, W // 2))
+        if d.mode == "downsample3d" and T > 1:
+            if (T - 1) % 2:
+                raise ValueError(f"temporal downsample needs an odd frame count at this stage, got {T}")
+            parts = []
+            for b in range(B):  # frame 0 is exempt; frame t >= 1 = conv(x[2t-2 .. 2t]) (chunked upstream form, whole sequence)
+                xb = x[b:b + 1]
+                y = self._conv_strided(xb, d.time_conv, (2, 1, 1), ((T - 1) // 2, H // 2, W // 2))
+                parts.append(torch.cat([xb[:, :1], y], dim=1))
+            x = torch.cat(parts, dim=0) if B > 1 else parts[0]
+        return x
+
+    @torch.no_grad()
+    def encode(self, video: torch.Tensor, return_dict: bool = True):
+        """video [B, 3, 1+4k, 8h, 8w] in [-1, 1] -> posterior over [B, z_dim, 1+k, h, w] (`.latent_dist`)."""
+        if not self._has_encoder:
+            raise RuntimeError("this VAE checkpoint carries no encoder tensors (decoder-only)")
+        B, C, T, H, W = video.shape
+        if C != 3 or (T - 1) % 4 or H % 8 or W % 8:
+            raise ValueError(f"encode expects [B, 3, 1+4k, 8h, 8w], got {tuple(video.shape)}")
+        e = self.encoder
+        x = torch.zeros((B, T, H, W, 64), dtype=BF16, device=video.device)
+        x[..., :3] = video.to(BF16).permute(0, 2, 3, 4, 1)
+        x = self._conv(x, e.conv_in)
+        for blk in e.down_blocks:
+            x = self._res(x, blk) if isinstance(blk, _Res) else self._downsample(x, blk)
+        x = self._res(x, e.mid_block.resnets[0])
+        x = self._attn(x, e.mid_block.attentions[0])
+        x = self._res(x, e.mid_block.resnets[1])
+        x = self._conv(self._norm(x, e.norm_out), e.conv_out)
+        x = self._conv(x, self.quant_conv)
+        zz = 2 * self.config.z_dim
+        params = x[..., :zz].permute(0, 4, 1, 2, 3).contiguous().to(self.dtype)
+        dist = DiagonalGaussianDistribution(params)
+        if return_dict:
+            return SimpleNamespace(latent_dist=dist)
+        return (dist,)
 
     @torch.no_grad()
     def decode(self, z: torch.Tensor, return_dict: bool = False):

@@ -1,4 +1,4 @@
-"""CPU oracle for the WAN-style causal 3-D VAE decoder (TEST INFRASTRUCTURE — never imported by the product).
+"""CPU oracle for the WAN-style causal 3-D VAE decoder and encoder (TEST INFRASTRUCTURE — never imported by the product).
 
 **Parity unpinned**: `AutoencoderKLWan` belongs to the un-vendored upstream package; the reference
 only fixes the contract around it — `vae.decode(z.to(vae.dtype), return_dict=False)[0]` in [-1, 1],
@@ -9,7 +9,13 @@ attention, causal 3x3x3 convs, channel RMS norm, nearest-exact 2x upsample + 3x3
 (3,1,1) causal conv to 2C channels whose halves become consecutive frames — with the FIRST latent frame exempt from
 temporal upsampling (it decodes to 1 frame, every later latent frame to 4).
 
-Two formulations are given and must agree (tests/test_vae_oracle.py):
+The encoder (second half of this file) restates the published WAN-2.1 encoder the same way [assumed-from-upstream]:
+conv_in 3 -> 96, per stage 2 residual blocks then a downsampler (ZeroPad2d((0,1,0,1)) + 3x3 stride-2 conv per frame; for
+"downsample3d" followed by a (3,1,1) stride-2 temporal conv from which the FIRST frame is exempt), mid block, RMS norm + SiLU,
+conv_out -> 2 z_dim, 1x1x1 quant_conv, posterior mean = first z_dim channels (the reference takes the mode:
+`retrieve_latents(vae.encode(x))`, delta_experiment/scripts/common.py:158-174).  `[1,3,1+4k,8h,8w] -> [1,16,1+k,h,w]`.
+
+Two formulations are given and must agree (tests/test_vae_oracle.py), for the decoder and for the encoder:
   * `decode_chunked`  — frame-by-frame with feature caches, the way the upstream module streams it;
   * `decode_full`     — the whole sequence at once with causal zero padding (what the HIP decoder implements; a
                         288 GB device has no need for the chunk loop).
@@ -238,3 +244,141 @@ def decode_chunked(P, cfg, z):
         x = _conv_cached(P, "decoder.conv_out", x, cache, idx)
         outs.append(x)
     return torch.cat(outs, dim=2).clamp(-1.0, 1.0)
+
+
+# =========================================================================== encoder
+def encoder_plan(cfg):
+    """Flat list of ("res", in_dim, out_dim) / ("down2d" | "down3d", dim) entries = upstream `encoder.down_blocks`."""
+    dim, mult = cfg["base_dim"], cfg["dim_mult"]
+    dims = [dim * u for u in [1] + mult]
+    t_down = cfg["temperal_downsample"]
+    plan = []
+    for i, (i_d, o_d) in enumerate(zip(dims[:-1], dims[1:])):
+        for _ in range(cfg["num_res_blocks"]):
+            plan.append(("res", i_d, o_d))
+            i_d = o_d
+        if i != len(mult) - 1:
+            plan.append(("down3d" if t_down[i] else "down2d", o_d))
+    return dims, plan
+
+
+def make_encoder_params(cfg, seed=1, std=0.05, dtype=torch.bfloat16) -> Dict[str, torch.Tensor]:
+    g = torch.Generator().manual_seed(seed)
+    P = {}
+
+    def conv(name, co, ci, *k):
+        fan = ci
+        for kk in k:
+            fan *= kk
+        P[name + ".weight"] = (torch.randn(co, ci, *k, generator=g) * (1.0 / fan ** 0.5)).to(dtype)
+        P[name + ".bias"] = (torch.randn(co, generator=g) * std).to(dtype)
+
+    def norm(name, c, images=False):
+        shape = (c, 1, 1) if images else (c, 1, 1, 1)
+        P[name + ".gamma"] = (1.0 + 0.1 * torch.randn(shape, generator=g)).to(dtype)
+
+    def res(name, ci, co):
+        norm(name + ".norm1", ci); conv(name + ".conv1", co, ci, 3, 3, 3)
+        norm(name + ".norm2", co); conv(name + ".conv2", co, co, 3, 3, 3)
+        if ci != co:
+            conv(name + ".conv_shortcut", co, ci, 1, 1, 1)
+
+    z = cfg["z_dim"]
+    dims, plan = encoder_plan(cfg)
+    conv("encoder.conv_in", dims[0], 3, 3, 3, 3)
+    for k, item in enumerate(plan):
+        name = f"encoder.down_blocks.{k}"
+        if item[0] == "res":
+            res(name, item[1], item[2])
+        else:
+            conv(name + ".resample.1", item[1], item[1], 3, 3)
+            if item[0] == "down3d":
+                conv(name + ".time_conv", item[1], item[1], 3, 1, 1)
+    top = dims[-1]
+    res("encoder.mid_block.resnets.0", top, top)
+    norm("encoder.mid_block.attentions.0.norm", top, images=True)
+    conv("encoder.mid_block.attentions.0.to_qkv", 3 * top, top, 1, 1)
+    conv("encoder.mid_block.attentions.0.proj", top, top, 1, 1)
+    res("encoder.mid_block.resnets.1", top, top)
+    norm("encoder.norm_out", top)
+    conv("encoder.conv_out", 2 * z, top, 3, 3, 3)
+    conv("quant_conv", 2 * z, 2 * z, 1, 1, 1)
+    return P
+
+
+def spatial_down_conv(P, name, x, rnd):
+    """ZeroPad2d((0, 1, 0, 1)) + Conv2d(3x3, stride 2) on every frame."""
+    b, c, t, h, w = x.shape
+    y = x.permute(0, 2, 1, 3, 4).reshape(b * t, c, h, w)
+    y = F.pad(y, (0, 1, 0, 1))
+    y = _bf(F.conv2d(y, P[name + ".resample.1.weight"].float(), P[name + ".resample.1.bias"].float(), stride=2), rnd)
+    return y.view(b, t, y.shape[1], y.shape[2], y.shape[3]).permute(0, 2, 1, 3, 4)
+
+
+def temporal_down_full(P, name, x, rnd):
+    """Whole-sequence form of the chunked temporal downsample: frame 0 passes, frame t >= 1 = conv(x[2t-2 .. 2t])."""
+    if x.shape[2] == 1:
+        return x
+    w, b = P[name + ".time_conv.weight"].float(), P[name + ".time_conv.bias"].float()
+    y = _bf(F.conv3d(x, w, b, stride=(2, 1, 1)), rnd)   # windows start at frames 0, 2, 4, ...
+    return torch.cat([x[:, :, :1], y], dim=2)
+
+
+def encode_full(P, cfg, video, rnd=False):
+    """Whole-sequence encode: video [B, 3, 1+4k, H, W] in [-1, 1] -> posterior mean [B, z_dim, 1+k, H/8, W/8]."""
+    dims, plan = encoder_plan(cfg)
+    x = _bf(video.float(), rnd)
+    x = _bf(causal_conv3d(x, P["encoder.conv_in.weight"], P["encoder.conv_in.bias"]), rnd)
+    for k, item in enumerate(plan):
+        name = f"encoder.down_blocks.{k}"
+        if item[0] == "res":
+            x = res_block_full(P, name, x, rnd)
+        else:
+            x = spatial_down_conv(P, name, x, rnd)
+            if item[0] == "down3d":
+                x = temporal_down_full(P, name, x, rnd)
+    x = res_block_full(P, "encoder.mid_block.resnets.0", x, rnd)
+    x = mid_attention(P, "encoder.mid_block.attentions.0", x, rnd)
+    x = res_block_full(P, "encoder.mid_block.resnets.1", x, rnd)
+    x = _bf(F.silu(rms_norm(x, P["encoder.norm_out.gamma"])), rnd)
+    x = _bf(causal_conv3d(x, P["encoder.conv_out.weight"], P["encoder.conv_out.bias"]), rnd)
+    x = _bf(causal_conv3d(x, P["quant_conv.weight"], P["quant_conv.bias"]), rnd)
+    return x[:, : cfg["z_dim"]]
+
+
+def encode_chunked(P, cfg, video):
+    """The upstream streaming order: frame 0 alone, then 4 frames per call, per-conv feature caches (fp32)."""
+    dims, plan = encoder_plan(cfg)
+    cache: List[Optional[object]] = [None] * 64
+    T = video.shape[2]
+    outs = []
+    for it in range(1 + (T - 1) // 4):
+        idx = [0]
+        x = video[:, :, :1].float() if it == 0 else video[:, :, 1 + 4 * (it - 1):1 + 4 * it].float()
+        x = _conv_cached(P, "encoder.conv_in", x, cache, idx)
+        for k, item in enumerate(plan):
+            name = f"encoder.down_blocks.{k}"
+            if item[0] == "res":
+                x = _res_block_chunk(P, name, x, cache, idx)
+            else:
+                x = spatial_down_conv(P, name, x, False)
+                if item[0] == "down3d":
+                    j = idx[0]
+                    if cache[j] is None:
+                        cache[j] = x.clone()          # first chunk: cached, not convolved
+                    else:
+                        last = x[:, :, -1:].clone()
+                        xin = torch.cat([cache[j][:, :, -1:], x], dim=2)
+                        x = F.conv3d(xin, P[name + ".time_conv.weight"].float(), P[name + ".time_conv.bias"].float(),
+                                     stride=(2, 1, 1))
+                        cache[j] = last
+                    idx[0] += 1
+        x = _res_block_chunk(P, "encoder.mid_block.resnets.0", x, cache, idx)
+        x = mid_attention(P, "encoder.mid_block.attentions.0", x, False)
+        x = _res_block_chunk(P, "encoder.mid_block.resnets.1", x, cache, idx)
+        x = F.silu(rms_norm(x, P["encoder.norm_out.gamma"]))
+        x = _conv_cached(P, "encoder.conv_out", x, cache, idx)
+        outs.append(x)
+    x = torch.cat(outs, dim=2)
+    x = causal_conv3d(x, P["quant_conv.weight"], P["quant_conv.bias"])
+    return x[:, : cfg["z_dim"]]

@@ -1,5 +1,5 @@
-"""GPU parity of the HIP VAE decoder against the CPU oracle (oracle/vae_oracle.decode_full at the same bf16 rounding
-points).  Tolerance: relative L2 <= 2e-2 on the clamped video after ~30 bf16-rounded conv/norm stages (the oracle's own
+"""GPU parity of the HIP VAE decoder and encoder against the CPU oracle (oracle/vae_oracle.{decode,encode}_full at the same
+bf16 rounding points).  Tolerance: relative L2 <= 2e-2 on the clamped video after ~30 bf16-rounded conv/norm stages (the oracle's own
 bf16-vs-fp32 gap is printed for scale)."""
 import pytest
 import torch
@@ -13,7 +13,13 @@ BF16 = torch.bfloat16
 def _build(cfg, P):
     from longcat_video.modules.autoencoder_kl_wan import AutoencoderKLWan
     vae = AutoencoderKLWan(base_dim=cfg["base_dim"], z_dim=cfg["z_dim"], device="cuda", dtype=BF16)
-    missing, unexpected = vae.load_state_dict(P, strict=False)
+    from oracle import vae_oracle as V
+    full = dict(P)
+    for k, v in V.make_encoder_params(cfg, seed=5).items():
+        full.setdefault(k, v)
+    for k, v in V.make_params(cfg, seed=3).items():
+        full.setdefault(k, v)
+    missing, unexpected = vae.load_state_dict(full, strict=False)
     assert not missing and not unexpected, (missing, unexpected)
     return vae
 
@@ -60,3 +66,65 @@ def test_vae_decode_matches_oracle(T):
     print(f"vae decode rel_l2 hip-vs-oracle = {e:.2e}; oracle bf16-vs-fp32 = {rel_l2(ref, ref32):.2e}")
     assert e < 2e-2
     assert got.min() >= -1 and got.max() <= 1
+
+
+def test_strided_conv_kernel_against_torch():
+    """The encoder's two downsampling convs: ZeroPad2d((0,1,0,1)) + 3x3 stride 2 per frame, and (3,1,1) stride 2 in time."""
+    import torch.nn.functional as F
+    from longcat_video.modules.vae_wan import AutoencoderKLWan, _Conv
+    vae = AutoencoderKLWan(base_dim=16, z_dim=4, device="cuda", dtype=BF16)
+    g = torch.Generator().manual_seed(1)
+    ci = co = 64
+    for (H, W) in ((6, 10), (7, 9)):
+        conv = _Conv(ci, co, (3, 3), device="cuda", dtype=BF16)
+        with torch.no_grad():
+            conv.weight.copy_(torch.randn((co, ci, 3, 3), generator=g) * (ci * 9) ** -0.5); conv.bias.copy_(torch.randn(co, generator=g) * 0.1)
+        x = torch.randn(1, 3, H, W, ci, generator=g).to(BF16)
+        got = vae._conv_strided(x.cuda(), conv, (1, 2, 2), (3, H // 2, W // 2)).float().cpu()
+        y = F.pad(x.float().permute(0, 1, 4, 2, 3).reshape(3, ci, H, W), (0, 1, 0, 1))
+        ref = F.conv2d(y, conv.weight.float().cpu(), conv.bias.float().cpu(), stride=2)
+        assert ref.shape[-2:] == (H // 2, W // 2)
+        assert rel_l2(got, ref.view(1, 3, co, H // 2, W // 2).permute(0, 1, 3, 4, 2)) < 3e-3
+    conv = _Conv(ci, co, (3, 1, 1), device="cuda", dtype=BF16)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn((co, ci, 3, 1, 1), generator=g) * (ci * 3) ** -0.5); conv.bias.copy_(torch.randn(co, generator=g) * 0.1)
+    x = torch.randn(1, 9, 4, 5, ci, generator=g).to(BF16)
+    got = vae._conv_strided(x.cuda(), conv, (2, 1, 1), (4, 4, 5)).float().cpu()
+    ref = F.conv3d(x.float().permute(0, 4, 1, 2, 3), conv.weight.float().cpu(), conv.bias.float().cpu(), stride=(2, 1, 1))
+    assert rel_l2(got, ref.permute(0, 2, 3, 4, 1)) < 3e-3
+
+
+@pytest.mark.parametrize("k", [0, 2])
+def test_vae_encode_matches_oracle(k):
+    from oracle import vae_oracle as V
+    cfg = V.default_config(base_dim=16, z_dim=4)
+    P = V.make_encoder_params(cfg, seed=5)
+    vae = _build(cfg, P)
+    g = torch.Generator().manual_seed(6)
+    video = (torch.rand(1, 3, 1 + 4 * k, 32, 48, generator=g) * 2 - 1).to(BF16)
+    post = vae.encode(video.cuda()).latent_dist
+    got = post.mode()
+    Pf = {n: v.float() for n, v in P.items()}
+    ref = V.encode_full(Pf, cfg, video, rnd=True)
+    ref32 = V.encode_full(Pf, cfg, video, rnd=False)
+    assert got.shape == ref.shape == (1, 4, 1 + k, 4, 6)
+    e = rel_l2(got, ref)
+    print(f"vae encode rel_l2 hip-vs-oracle = {e:.2e}; oracle bf16-vs-fp32 = {rel_l2(ref, ref32):.2e}")
+    assert e < 2e-2
+    # the posterior surface the reference reads: mode() is the mean; sample() is mean + std * eps from the given generator
+    from longcat_video.pipeline_longcat_video import retrieve_latents
+    assert torch.equal(retrieve_latents(vae.encode(video.cuda())), got)
+    g1 = torch.Generator(device="cuda").manual_seed(7); g2 = torch.Generator(device="cuda").manual_seed(7)
+    assert torch.equal(post.sample(g1), post.sample(g2)) and post.logvar.max() <= 20 and post.logvar.min() >= -30
+
+
+def test_vae_encode_rejects_bad_shapes_and_decoder_only_checkpoints():
+    from longcat_video.modules.autoencoder_kl_wan import AutoencoderKLWan
+    vae = AutoencoderKLWan(base_dim=16, z_dim=4, device="cuda", dtype=BF16).init_synthetic_()
+    with pytest.raises(ValueError):
+        vae.encode(torch.zeros(1, 3, 4, 32, 32, device="cuda", dtype=BF16))   # T != 1 + 4k
+    with pytest.raises(ValueError):
+        vae.encode(torch.zeros(1, 3, 5, 30, 32, device="cuda", dtype=BF16))   # H % 8
+    vae._has_encoder = False
+    with pytest.raises(RuntimeError):
+        vae.encode(torch.zeros(1, 3, 5, 32, 32, device="cuda", dtype=BF16))
