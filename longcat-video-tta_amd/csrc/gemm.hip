@@ -568,6 +568,20 @@ __global__ __launch_bounds__(WR* WC * 64) void gemm16_nt_kernel(const GemmParams
 //   RAW: the wait of phase p (before its first barrier) retires everything but the 4 newest half-tiles, which always
 //        includes every slot phase p+1 reads; the reader passes at least one more barrier than any waiter.
 // ---------------------------------------------------------------------------
+#ifdef LCV_GEMM_STAMPS  // scratch/gemm_lab only: s_memtime at every barrier arrival / release of one workgroup
+__device__ unsigned long long* g_gdbg = nullptr;
+#define GSTAMP()                                                                                      \
+  do {                                                                                                \
+    if (gdbg_on && gdbg_n < 512) {                                                                    \
+      const unsigned long long tnow__ = __builtin_amdgcn_s_memtime();                                 \
+      if (lane == 0) gdbg_p[(wave ? 512 : 0) + gdbg_n] = tnow__;                                      \
+      ++gdbg_n;                                                                                       \
+    }                                                                                                 \
+  } while (0)
+#else
+#define GSTAMP() do {} while (0)
+#endif
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -591,6 +605,11 @@ __global__ __launch_bounds__(512) void gemm8p_nt_kernel(const GemmParams p) {
   const int wr = wave >> 2, wc = wave & 3;
   const int r16 = lane & 15, q = lane >> 4;
   const int nwg = p.tiles_m * p.tiles_n;
+#ifdef LCV_GEMM_STAMPS
+  int gdbg_n = 0;
+  unsigned long long* const gdbg_p = g_gdbg;
+  const bool gdbg_on = gdbg_p != nullptr && blockIdx.x == 100 && (wave == 0 || wave == 4);
+#endif
 
   // ---- LDS-DMA roles: instruction t of wave w fills slot rows 8 (2 w + t) .. +8; lane -> row (lane >> 3), 16-B position
   // (lane & 7) which holds logical chunk (lane & 7) ^ ((row >> 1) & 7).  Per-lane state is the (clamped) global row of
@@ -693,8 +712,11 @@ __global__ __launch_bounds__(512) void gemm8p_nt_kernel(const GemmParams p) {
       if constexpr (P == 4) stage_w(C0{}, kt + 2, buf);
     }
     if constexpr (VM >= 0) wait_vmcnt<VM>();
+    GSTAMP();
     __builtin_amdgcn_s_barrier();
+    GSTAMP();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    GSTAMP();
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
     constexpr int mq = (P >= 3) ? 1 : 0;
@@ -709,7 +731,9 @@ __global__ __launch_bounds__(512) void gemm8p_nt_kernel(const GemmParams p) {
               __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nq][j][ks], af[i][ks], acc[4 * mq + i][2 * nq + j], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
+    GSTAMP();
     __builtin_amdgcn_s_barrier();
+    GSTAMP();
   };
   using V8 = std::integral_constant<int, 8>;
   using V6 = std::integral_constant<int, 6>;
