@@ -197,8 +197,8 @@ class LongCatVideoTransformer3DModel(nn.Module):
                 x = self._gradient_checkpointing_func(block, x, y, t, y_seqlens, (N_t, N_h, N_w), **kw)
             else:
                 x = block(x, y, t, y_seqlens, (N_t, N_h, N_w), **kw)
-        if return_kv:
-            return x, kv_out
         x = self.final_layer(x, t, (N_t, N_h, N_w))
         x = self.unpatchify(x, N_t, N_h, N_w)
+        if return_kv:  # (prediction, per-block K/V): element 0 keeps the output's shape so output hooks (run_delta_c.py:121-133) apply
+            return x.to(torch.float32), kv_out
         return x.to(torch.float32)

@@ -133,7 +133,13 @@ class DeltaCWrapper(_HookedWrapper):
     def apply_to_dit(self):
         self.remove_from_dit()
         d = self.delta_out
-        self._hooks.append(self.dit.register_forward_hook(lambda _m, _i, out: out + d.view(1, -1, 1, 1, 1).to(out.dtype)))
+
+        def _hook(_m, _i, out):  # the KV-cache pass returns (prediction, kv): run_delta_c.py:125-131
+            if isinstance(out, tuple):
+                return (out[0] + d.view(1, -1, 1, 1, 1).to(out[0].dtype),) + out[1:]
+            return out + d.view(1, -1, 1, 1, 1).to(out.dtype)
+
+        self._hooks.append(self.dit.register_forward_hook(_hook))
 
     def forward(self, hidden_states, timestep, encoder_hidden_states, encoder_attention_mask=None,
                 num_cond_latents=0, **kwargs):

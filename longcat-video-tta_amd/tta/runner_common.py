@@ -1,0 +1,251 @@
+"""What the per-method runner scripts share: the common CLI block, model / data loading (real
+checkpoints or `synthetic[:depth[:hidden[:caption]]]`; `latents/*.pt` or `synthetic:N` data), one-process-per-GPU data
+parallelism over videos, the KV-cached CFG continuation, and the reference's `checkpoint.json` / `summary.json` schemas
+(delta_experiment/scripts/run_delta_a.py:763-935, run_delta_b.py:915-960, run_delta_c.py:640-703;
+`save_checkpoint` common.py:2055-2059).  The LoRA runner has its own main (it also writes `config.json`)."""
+import json
+import os
+import time
+from pathlib import Path
+from typing import Callable, Dict, List
+
+import numpy as np
+import torch
+
+from longcat_video.parallel import data_parallel as dp
+from tta import cli_args as C
+from tta.early_stopping import add_early_stopping_args, build_early_stopper_from_args
+from tta.latent_split import _estimate_latent_len, num_frames_valid, split_tta_latents
+
+
+def add_common_args(p):
+    p.add_argument("--checkpoint-dir", type=str, required=True, help="checkpoint dir, or synthetic[:depth[:hidden[:caption]]]")
+    p.add_argument("--data-dir", type=str, required=True)
+    p.add_argument("--output-dir", type=str, required=True)
+    p.add_argument("--max-videos", type=int, default=100)
+    p.add_argument("--seed", type=int, default=42)
+    p.add_argument("--device", type=str, default="cuda")
+    p.add_argument("--num-cond-frames", type=int, default=2)
+    p.add_argument("--num-frames", type=int, default=16)
+    p.add_argument("--gen-start-frame", type=int, default=32)
+    p.add_argument("--num-inference-steps", type=int, default=50)
+    p.add_argument("--guidance-scale", type=float, default=4.0)
+    p.add_argument("--resolution", type=str, default="480p")
+    p.add_argument("--skip-generation", action="store_true")
+    p.add_argument("--no-save-videos", action="store_true")
+
+
+def add_shared_groups(p, clip_gate: bool = True):
+    add_early_stopping_args(p)
+    C.add_augmentation_args(p)
+    C.add_tta_frame_args(p)
+    C.add_caption_guard_args(p)
+    C.add_caption_override_args(p)
+    C.add_feature_frame_guard_args(p)
+    C.add_online_eval_args(p)
+    if clip_gate:
+        C.add_clip_gate_args(p)
+
+
+def setup_distributed(args):
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl")
+    device = f"cuda:{local_rank}" if args.device.startswith("cuda") else args.device
+    return rank, world, device
+
+
+def load_components(args, device):
+    from longcat_video.modules.longcat_video_dit import LongCatVideoTransformer3DModel
+    from longcat_video.modules.scheduling_flow_match_euler_discrete import FlowMatchEulerDiscreteScheduler
+    from longcat_video.pipeline_longcat_video import LongCatVideoPipeline
+    ck = args.checkpoint_dir
+    if ck.startswith("synthetic"):
+        kw = {}
+        if ":" in ck:  # synthetic:depth[:hidden[:caption]] — reduced sizes are for plumbing tests only
+            parts = ck.split(":")[1:]
+            kw["depth"] = int(parts[0])
+            if len(parts) > 1:
+                kw.update(hidden_size=int(parts[1]), num_heads=int(parts[1]) // 128)
+            if len(parts) > 2:
+                kw.update(caption_channels=int(parts[2]))
+        dit = LongCatVideoTransformer3DModel(device=device, dtype=torch.bfloat16, **kw).init_synthetic_(1234)
+        sched, vae = FlowMatchEulerDiscreteScheduler(), None
+    else:
+        dit = LongCatVideoTransformer3DModel.from_pretrained(ck, subfolder="dit", cp_split_hw=[1, 1],
+                                                             enable_flashattn2=True, torch_dtype=torch.bfloat16).to(device)
+        sched = FlowMatchEulerDiscreteScheduler.from_pretrained(ck, subfolder="scheduler")
+        from longcat_video.modules.autoencoder_kl_wan import AutoencoderKLWan
+        vae = AutoencoderKLWan.from_pretrained(ck, subfolder="vae", torch_dtype=torch.bfloat16).to(device)
+    pipe = LongCatVideoPipeline(vae=vae, scheduler=sched, dit=dit)
+    pipe.device = torch.device(device)
+    return dit, pipe
+
+
+def list_eval_entries(args, dit):
+    d = args.data_dir
+    if d.startswith("synthetic"):
+        n = int(d.split(":")[1]) if ":" in d else 4
+        return [{"kind": "synthetic", "name": f"synthetic_{i:04d}", "path": f"synthetic://{i}", "seed": 1000 + i}
+                for i in range(min(n, args.max_videos))]
+    lat = Path(d) / "latents"
+    if lat.is_dir():
+        files = sorted(lat.glob("*.pt"))[: args.max_videos]
+        return [{"kind": "latents", "name": f.stem, "path": str(f)} for f in files]
+    vids = sorted(p for p in Path(d).rglob("*") if p.suffix.lower() in (".mp4", ".avi", ".mkv"))[: args.max_videos]
+    return [{"kind": "video", "name": v.stem, "path": str(v)} for v in vids]
+
+
+def load_entry(entry, args, dit, device, total_frames=None):
+    h, w = {"480p": (60, 104), "720p": (90, 160)}[args.resolution]
+    if entry["kind"] == "synthetic":
+        T = _estimate_latent_len(total_frames if total_frames is not None else args.tta_total_frames)
+        g = torch.Generator(device=device).manual_seed(entry["seed"])
+        cy = dit.config.caption_channels
+        lat = torch.randn((1, dit.config.in_channels, T, h, w), generator=g, device=device).to(torch.bfloat16)
+        pe = torch.randn((1, 1, 512, cy), generator=g, device=device).to(torch.bfloat16)
+        pm = torch.zeros((1, 512), dtype=torch.int64, device=device); pm[:, :77] = 1
+        return dict(latents=lat, prompt_embeds=pe, prompt_mask=pm, negative_embeds=torch.zeros_like(pe), negative_mask=pm,
+                    caption="synthetic")
+    if entry["kind"] == "latents":
+        blob = torch.load(entry["path"], map_location=device)
+        blob.setdefault("caption", "")
+        return blob
+    raise NotImplementedError("raw-video input needs the PyAV decode + UMT5 rows that precede the hot path "
+                              "(SURVEY §8(f)); pre-encode to <data-dir>/latents/*.pt")
+
+
+def generate_continuation(pipe, blob, args, idx, device, num_frames=None):
+    """KV-cached CFG continuation from the clean conditioning latents (what `generate_video_continuation`,
+    common.py:566-611, does after its VAE encode).  Returns (denoised latents, seconds)."""
+    t0 = time.time()
+    n_valid = num_frames_valid(num_frames if num_frames is not None else args.num_frames)
+    T_lat = _estimate_latent_len(n_valid)
+    ncl = _estimate_latent_len(args.num_cond_frames)
+    g = torch.Generator(device=device).manual_seed(args.seed + idx)
+    lat0 = blob["latents"]
+    lat = torch.randn((1, lat0.shape[1], T_lat) + tuple(lat0.shape[3:]), generator=g, device=device, dtype=torch.float32)
+    lat[:, :, :ncl] = lat0[:, :, -ncl:].float()
+    out = pipe.denoise(lat, blob["prompt_embeds"], blob["prompt_mask"], blob.get("negative_embeds"), blob.get("negative_mask"),
+                       num_cond_latents=ncl, num_inference_steps=args.num_inference_steps,
+                       guidance_scale=args.guidance_scale, use_kv_cache=True)
+    torch.cuda.synchronize()
+    return out, time.time() - t0
+
+
+def save_frames(pipe, latents, path_noext: str):
+    frames = pipe._decode_to_numpy(latents)
+    np.save(path_noext + ".npy", (frames * 255).astype(np.uint8))
+    return path_noext + ".npy"
+
+
+def clip_gate_summary(args) -> Dict:
+    return {"clip_gate_enabled": args.clip_gate_enabled, "clip_gate_threshold": args.clip_gate_threshold,
+            "clip_gate_backend": args.clip_gate_backend, "clip_gate_model": args.clip_gate_model,
+            "clip_gate_sample_frames": args.clip_gate_sample_frames, "clip_gate_aggregation": args.clip_gate_aggregation,
+            "clip_gate_sampling_mode": "late_only" if args.clip_gate_late_only else args.clip_gate_sampling_mode,
+            "clip_gate_late_fraction": args.clip_gate_late_fraction, "clip_gate_log_only": args.clip_gate_log_only,
+            "clip_gate_fail_open": args.clip_gate_fail_open,
+            "clip_gate_stats": {"skip_rate": 0.0, "num_skipped": 0, "num_scored": 0}}
+
+
+def run_delta_method(args, method: str, make_wrapper: Callable, optimize_fn: Callable, params_of: Callable,
+                     result_extra: Callable, summary_head: Dict, file_suffix: str):
+    """The per-video loop of the delta runners: fresh wrapper -> (anchored early stopping) -> optimise on the conditioning
+    window -> continuation with the wrapper's hooks installed -> checkpoint after every video -> summary."""
+    C.normalize_tta_frame_args(args)
+    C.validate_tta_feature_budget(args, context=method)
+    C.reject_out_of_scope(args)
+    if getattr(args, "batch_videos", 1) != 1:
+        raise NotImplementedError("retrieval-augmented batch TTA needs the sentence-transformer pool (SURVEY §2 #16)")
+    rank, world, device = setup_distributed(args)
+    torch.manual_seed(args.seed)
+    np.random.seed(args.seed)
+    os.makedirs(args.output_dir, exist_ok=True)
+    videos_dir = os.path.join(args.output_dir, "videos"); os.makedirs(videos_dir, exist_ok=True)
+    prior = dp.load_checkpoint(args.output_dir, rank if world > 1 else None)
+    all_results = prior["results"] if prior else []
+    done = {r["idx"] for r in all_results}
+    dit, pipe = load_components(args, device)
+    for p in dit.parameters():
+        p.requires_grad = False
+    entries = list_eval_entries(args, dit)
+    my_idx = [i for i in dp.shard_indices(len(entries), rank, world) if i not in done]
+    early_stopper = build_early_stopper_from_args(args)
+    n_ctx_lat = _estimate_latent_len(args.tta_context_frames)
+    from tta.inner_loop import choose_gradient_checkpointing
+
+    for idx in my_idx:
+        e = entries[idx]
+        try:
+            torch.manual_seed(dp.seed_for_video(args.seed, idx))
+            blob = load_entry(e, args, dit, device)
+            cond, train, val = split_tta_latents(blob["latents"], n_ctx_lat, args.es_holdout_fraction)
+            n_tok = (cond.shape[2] + train.shape[2]) * (cond.shape[3] // 2) * (cond.shape[4] // 2)
+            choose_gradient_checkpointing(dit, n_tok)
+            wrapper = make_wrapper(dit).to(device)
+            pe, pm = blob["prompt_embeds"], blob["prompt_mask"]
+            es = early_stopper if (early_stopper is not None and val is not None) else None
+            if es is not None:
+                import copy
+                es.setup(model=wrapper, cond_latents=cond, val_latents=val, prompt_embeds=pe, prompt_mask=pm, device=device,
+                         dtype=torch.bfloat16,
+                         forward_fn=lambda hs, ts, ncl: wrapper(hidden_states=hs, timestep=ts, encoder_hidden_states=pe,
+                                                                encoder_attention_mask=pm, num_cond_latents=ncl),
+                         video_id=e["name"], save_fn=lambda: [copy.deepcopy(p.data) for p in params_of(wrapper)])
+            t0 = time.time()
+            opt = optimize_fn(wrapper, cond, train, pe, pm, device, es)
+            torch.cuda.synchronize()
+            train_time = time.time() - t0
+            result = {"idx": idx, "video_name": e["name"], "video_path": e["path"], "caption": blob.get("caption", ""),
+                      "train_time": train_time, "es_check_time": opt.get("es_check_time", 0.0),
+                      "final_loss": opt["losses"][-1] if opt["losses"] else None, "batch_size": 1, "num_neighbors": 0,
+                      "early_stopping_info": opt.get("early_stopping_info"), "success": True}
+            result.update(result_extra(opt))
+            gen_time = 0.0
+            if not args.skip_generation:
+                wrapper.apply_to_dit()
+                try:
+                    out, gen_time = generate_continuation(pipe, blob, args, idx, device)
+                finally:
+                    wrapper.remove_from_dit()
+                result["gen_time"] = gen_time
+                if pipe.vae is not None and not args.no_save_videos:
+                    result["output_path"] = save_frames(pipe, out, os.path.join(videos_dir, f"{e['name']}_{file_suffix}"))
+            result["total_time"] = train_time + gen_time
+            print(f"  [{idx}] {e['name']}: train {train_time:.1f}s loss {result['final_loss']}"
+                  + (f" gen {gen_time:.1f}s" if not args.skip_generation else ""))
+            all_results.append(result)
+        except Exception as ex:  # recorded and skipped, like the reference (run_delta_a.py:881-893)
+            import traceback
+            print(f"  ERROR: {ex}")
+            traceback.print_exc()
+            all_results.append({"idx": idx, "video_name": e["name"], "video_path": e["path"], "error": str(ex),
+                                "success": False})
+        dp.write_checkpoint(args.output_dir, idx + world, all_results, rank=rank if world > 1 else None)
+
+    merged = dp.gather_results(all_results) if world > 1 else dp.merge_results([all_results])
+    if rank == 0:
+        ok = [r for r in merged if r.get("success", False)]
+        mean = lambda k: float(np.mean([r.get(k, 0.0) or 0.0 for r in ok])) if ok else 0
+        summary = {"method": method}
+        summary.update(summary_head)
+        summary.update({"num_cond_frames": args.num_cond_frames, "num_frames": args.num_frames,
+                        "gen_start_frame": args.gen_start_frame, "num_videos": len(merged), "num_successful": len(ok),
+                        "avg_train_time": mean("train_time"), "avg_clip_gate_eval_time": 0,
+                        "avg_es_check_time": mean("es_check_time"), "avg_gen_time": mean("gen_time"),
+                        "avg_total_time": mean("total_time")})
+        if hasattr(args, "clip_gate_enabled"):
+            summary.update(clip_gate_summary(args))
+        summary["results"] = merged
+        dp.write_checkpoint(args.output_dir, dp.contiguous_next_idx(merged), merged)
+        with open(os.path.join(args.output_dir, "summary.json"), "w") as f:
+            json.dump(summary, f, indent=2, default=str)
+        print(f"{method} complete: {len(ok)}/{len(merged)} videos")
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()

@@ -30,7 +30,7 @@ struct AttnFwdParams {
   int H;
   int64_t q_sb, q_sn, q_sh, k_sb, k_sn, k_sh, v_sb, v_sn, v_sh, o_sb, o_sn, o_sh;
   float scale, scale_log2e;
-  int gx, xcd_remap, prio_all;  // q-blocks per (b,h); head-per-XCD block order when (B*H) % 8 == 0
+  int gx, xcd_remap, prio_all, prio_sm, prio_mm;  // q-blocks per (b,h); head-per-XCD block order when (B*H) % 8 == 0
 };
 
 #define RESCALE_THR 6.0f  // log2 units: the running max may lag by up to 2^6 before O and l are rescaled
@@ -209,6 +209,13 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnFwdPara
       ++dbg_n;
     }
   };
+  auto set_prio = [&](int v) {
+    if (v == 0) __builtin_amdgcn_s_setprio(0);
+    else if (v == 1) __builtin_amdgcn_s_setprio(1);
+    else if (v == 2) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(3);
+  };
+  const bool stage_prio = p.prio_sm != p.prio_mm;
   auto stage_barrier = [&]() {
     __builtin_amdgcn_sched_barrier(0);
     stamp();
@@ -314,6 +321,7 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnFwdPara
       stage_barrier();
       if (has_next) dma_half(V_{}, t + 1, buf ^ 1);  // V(t-1)'s buffer: the trailing half finished PV(t-1) one stage ago
     }
+    if (stage_prio) set_prio(p.prio_sm);  // softmax (vector) stage
 
     // ---- mask keys past Nk (last tile only; wave-uniform branch) ----
     if (!has_next && (p.Nk & 63)) {
@@ -376,6 +384,7 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnFwdPara
       stage_barrier();
       if (t + 2 < nt) dma_half(K_{}, t + 2, buf);  // K(t)'s buffer: the trailing half finished QK^T(t) one stage ago
     }
+    if (stage_prio) set_prio(p.prio_mm);  // matrix stages
 
     // ---- O^T += V^T P^T ----
 #pragma unroll
@@ -468,6 +477,7 @@ extern "C" int lcv_attn_fwd(const void* q, const void* k, const void* v, void* o
   const char* xe = getenv("LCV_ATTN_XCD");  // A/B knob: 0 disables the head-per-XCD block order
   p.gx = (int)gx;
   { const char* pa = getenv("LCV_PRIO_ALL"); p.prio_all = pa ? pa[0] - '0' : 0; }
+  { const char* ps = getenv("LCV_PRIO_STAGE"); p.prio_sm = ps ? ps[0] - '0' : 0; p.prio_mm = ps ? ps[1] - '0' : 0; }
   p.xcd_remap = ((B * H) % 8 == 0 && gx >= 8 && !(xe && xe[0] == '0')) ? 1 : 0;
   const dim3 grid = p.xcd_remap ? dim3(gx * (unsigned)(H * B)) : dim3(gx, (unsigned)H, (unsigned)B);
   auto launch = [&](auto kern) -> int {

@@ -36,13 +36,13 @@ int main(int argc, char** argv) {
                         H * D, D, 0.08838834764f, nullptr);
   };
   unsigned long long* dbg; hipMalloc(&dbg, 512 * 8); hipMemset(dbg, 0, 512 * 8);
-  const char* vars[] = {"1", "1", "1", "1", "1", "1", "3", "3"};
-  const char* prios[] = {"0", "1", "2", "3", "4", "5", "0", "1"};
+  const char* vars[] = {"1", "1", "1", "3", "3", "3", "3", "3"};
+  const char* prios[] = {"00", "30", "31", "00", "30", "31", "21", "03"};
   int vi = 0;
   for (const char* v : vars) {
     setenv("LCV_ATTN_VAR", v, 1);
-    setenv("LCV_PRIO_ALL", prios[vi], 1);
-    printf("prio_all=%s ", prios[vi]); ++vi;
+    setenv("LCV_PRIO_STAGE", prios[vi], 1);
+    printf("prio_stage(sm,mm)=%s ", prios[vi]); ++vi;
     void* outp = (v[0] == '1') ? (void*)o_ref : (void*)o;
     unsigned long long* null = nullptr;
     hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), &null, sizeof(null));

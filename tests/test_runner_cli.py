@@ -49,3 +49,49 @@ def test_runner_parses_the_sbatch_flag_set():
     args2.clip_gate_enabled = True
     with pytest.raises(NotImplementedError):
         C.reject_out_of_scope(args2)
+
+
+# --------------------------------------------------------------------------- the other runners at the reference's paths
+_PKG = ROOT / "longcat-video-tta_amd"
+_COMMON = ["--checkpoint-dir", "/ckpt", "--data-dir", "/data", "--output-dir", "/out", "--max-videos", "100",
+           "--num-cond-frames", "14", "--num-frames", "28", "--gen-start-frame", "32", "--tta-total-frames", "32",
+           "--tta-context-frames", "14", "--num-inference-steps", "50", "--guidance-scale", "4.0", "--resolution", "480p",
+           "--seed", "42", "--no-save-videos", "--caption-guard-mode", "warn", "--feature-frame-guard-mode", "fail",
+           "--clip-gate-threshold", "0.0", "--min-fvd-videos", "256", "--es-check-every", "5", "--es-patience", "3"]
+
+
+def _load_script(rel):
+    path = _PKG / rel
+    assert path.is_file(), f"runner missing at the reference's relative path: {rel}"
+    spec = importlib.util.spec_from_file_location("runner_" + path.stem, path)
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+@pytest.mark.parametrize("rel,extra,check", [
+    ("delta_experiment/scripts/run_delta_a.py",
+     ["--delta-steps", "20", "--delta-lr", "1e-3", "--batch-videos", "1", "--batch-method", "similarity"],
+     lambda a: a.delta_steps == 20 and a.delta_lr == 1e-3 and a.retrieval_pool_dir is None),
+    ("delta_experiment/scripts/run_delta_b.py",
+     ["--delta-steps", "20", "--delta-lr", "1e-3", "--num-groups", "4", "--delta-target", "hidden", "--delta-target-blocks",
+      "last_4", "--delta-dim", "64"],
+     lambda a: a.num_groups == 4 and a.delta_target == "hidden" and a.delta_dim == 64 and a.delta_target_blocks == "last_4"),
+    ("delta_experiment/scripts/run_delta_c.py", ["--delta-steps", "10", "--delta-lr", "1e-2", "--delta-mode", "per_channel"],
+     lambda a: a.delta_mode == "per_channel" and a.delta_steps == 10),
+])
+def test_delta_runners_parse_the_sbatch_flag_sets(rel, extra, check):
+    """sweep_experiment/sbatch/run_sweep.sbatch:440-560 (METHOD=delta_a|delta_b|delta_c)."""
+    m = _load_script(rel)
+    args = m.build_parser().parse_args(_COMMON + extra)
+    assert check(args) and args.num_cond_frames == 14 and args.es_check_every == 5 and args.clip_gate_enabled is False
+
+
+def test_baseline_runner_parses_the_reference_flags():
+    """baseline_experiment/scripts/run_baseline.py:235-262."""
+    m = _load_script("baseline_experiment/scripts/run_baseline.py")
+    a = m.build_parser().parse_args(["--checkpoint-dir", "c", "--data-dir", "d", "--output-dir", "o", "--num-cond-frames", "2",
+                                     "--num-gen-frames", "14", "--gen-start-frame", "32", "--resolution", "720p",
+                                     "--num-inference-steps", "50", "--guidance-scale", "4.0", "--seed", "42", "--max-videos",
+                                     "100", "--save-videos"])
+    assert a.num_gen_frames == 14 and a.resolution == "720p" and a.save_videos
