@@ -95,6 +95,56 @@ def cpu_baseline(num_inference_steps: int) -> dict:
                       "the bf16 rounding points"}
 
 
+def measure_reference_point(dit, dev, pe, pm, ne, nm) -> dict:
+    """The ONE operating point the reference publishes numbers for: 480p, 14 conditioning + 14
+    generated frames (29-frame pipeline -> 8 latent frames: 4 clean + 4 noised = 6 240 noise tokens attending 12 480),
+    50 steps, CFG 4.0, KV cache -> 80.4 s / video (experimental_report.md:102); LoRA-TTA inner loop, 20 steps, r=8 on
+    qkv+proj of all 48 blocks, Tc=3 + Tt=1 latent frames (6 240 tokens) -> 84.2-85.1 s (experimental_report.md:325-329)."""
+    import gc
+    from longcat_video.modules.autoencoder_kl_wan import AutoencoderKLWan
+    from longcat_video.modules.scheduling_flow_match_euler_discrete import FlowMatchEulerDiscreteScheduler
+    from longcat_video.pipeline_longcat_video import LongCatVideoPipeline
+    from tta.inner_loop import choose_gradient_checkpointing, finetune_lora_on_conditioning
+    from tta.lora import inject_lora_into_dit, remove_lora_from_dit
+    out = {}
+    h, w = 60, 104
+    vae = AutoencoderKLWan(device=dev).init_synthetic_()
+    pipe = LongCatVideoPipeline(vae=vae, scheduler=FlowMatchEulerDiscreteScheduler(), dit=dit)
+    pipe.device = dev
+    g = torch.Generator(device=dev).manual_seed(11)
+    frames = torch.rand((1, 3, 13, 480, 832), generator=g, device=dev) * 2 - 1      # 13 of the 14 cond frames: 1 + 4k
+    lat = torch.randn((1, 16, 8, h, w), generator=g, device=dev, dtype=torch.float32)
+
+    def gen():
+        cond = vae.encode(frames.to(torch.bfloat16)).latent_dist.mode().float()      # [1,16,4,60,104]
+        x = lat.clone(); x[:, :, :4] = cond
+        z = pipe.denoise(x, pe, pm, ne, nm, num_cond_latents=4, num_inference_steps=50, guidance_scale=4.0, use_kv_cache=True)
+        return pipe._decode_to_numpy(z)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    video = gen()
+    torch.cuda.synchronize(); out["gen_s"] = time.perf_counter() - t0
+    out["gen_frames"] = int(video.shape[0])
+    out["gen_s_reference_h200"] = 80.4
+    del vae, pipe, video
+    gc.collect(); torch.cuda.empty_cache()
+    for p_ in dit.parameters():
+        p_.requires_grad = False
+    mods = inject_lora_into_dit(dit, rank=8, alpha=16.0, target_modules=["qkv", "proj"])
+    cond = torch.randn((1, 16, 3, h, w), generator=g, device=dev).to(torch.bfloat16)
+    train = torch.randn((1, 16, 1, h, w), generator=g, device=dev).to(torch.bfloat16)
+    choose_gradient_checkpointing(dit, 4 * (h // 2) * (w // 2))
+    kw = dict(lr=2e-4, warmup_steps=3, device=str(dev), dtype=torch.bfloat16)
+    finetune_lora_on_conditioning(dit, mods, cond, train, pe, pm, num_steps=1, **kw)   # warm-up (W^T copies)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    finetune_lora_on_conditioning(dit, mods, cond, train, pe, pm, num_steps=20, **kw)
+    torch.cuda.synchronize(); out["tta20_s"] = time.perf_counter() - t0
+    out["tta20_s_reference_h200"] = [84.2, 85.1]
+    out["per_video_s"] = out["gen_s"] + out["tta20_s"]
+    out["per_video_s_reference_h200"] = 167.6
+    remove_lora_from_dit(dit)
+    return out
+
+
 def measure_extras(dit, dev, T, h, w, pe, pm) -> dict:
     """VAE decode of the finished clip and the LoRA-TTA inner-loop step (lora_experiment config: r=8, alpha 16,
     qkv+proj on all 48 blocks, Tc=4 clean + Tt=3 noised latent frames at the bench resolution)."""
@@ -211,7 +261,11 @@ def main():
     # ---- extras (outside the timed region, rank 0 of a 1-GPU run): the other two legs of "wall-clock per TTA video" ----
     extras = {}
     if world == 1 and not args.no_extras and args.depth == 48:
-        extras = measure_extras(dit, dev, T, h, w, pe, pm)
+        import contextlib
+        with contextlib.redirect_stdout(sys.stderr):   # stdout carries exactly one JSON line
+            ref_point = measure_reference_point(dit, dev, pe, pm, ne, nm)
+            extras = measure_extras(dit, dev, T, h, w, pe, pm)
+        extras["reference_operating_point_480p_14c14g"] = {k: (round(v, 2) if isinstance(v, float) else v) for k, v in ref_point.items()}
         extras["wall_clock_per_tta_video_s_extrapolated"] = (
             20 * extras["tta_step_s"] + args.num_inference_steps * sec_per_step + extras["vae_decode_s"])
     per_gpu = T / (args.num_inference_steps * sec_per_step)
