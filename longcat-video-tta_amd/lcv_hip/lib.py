@@ -70,6 +70,9 @@ def load():
         raise LcvError(
             f"{_LIB_PATH} is missing: build it with `python __graft_entry__.py` (hipcc, gfx950). "
             "There is no fallback path.")
+    # torch first: it carries its own libamdhip64 under the soname this library links to; if the system ROCm copy were
+    # loaded before it, the process would hold two HIP runtimes and torch would then find no GPU
+    import torch  # noqa: F401
     lib = ctypes.CDLL(str(_LIB_PATH), mode=os.RTLD_NOW | getattr(os, "RTLD_LOCAL", 0))
     lib.lcv_version.restype = c_int
     lib.lcv_version.argtypes = []
