@@ -151,12 +151,14 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnFwdPara
     vdma[i] = vbase + dma_row[i] * p.v_sn + dma_col[i];
   }
   // issue the K (which = 0) or V (which = 1) rows of tile t into buffer buf; kdma / vdma point at this lane's rows of tile t
-  auto dma_half = [&](auto which_c, int t, int buf) {
+  // FULL: the caller knows tile t is a full 64-key tile (every tile but the last) - no ragged-row branch in its stream
+  auto dma_half = [&](auto which_c, int t, int buf, auto full_c) {
     constexpr int which = decltype(which_c)::value;
+    constexpr bool FULL = decltype(full_c)::value;
     lds_u8* dst = lds + buf * 2 * TILE_BYTES + which * TILE_BYTES + wave * 2048;
     const bf16_t** src = which ? vdma : kdma;
     const int64_t sn = which ? p.v_sn : p.k_sn;
-    if ((int64_t)t * 64 + 64 <= p.Nk) {
+    if (FULL || (int64_t)t * 64 + 64 <= p.Nk) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         __builtin_amdgcn_global_load_lds((gbl_void_t*)src[i], (lds_void_t*)(dst + 1024 * i), 16, 0, 0);
@@ -173,9 +175,9 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnFwdPara
   };
   using K_ = std::integral_constant<int, 0>;
   using V_ = std::integral_constant<int, 1>;
-  auto dma_tile = [&](int t, int buf) {
-    dma_half(K_{}, t, buf);
-    dma_half(V_{}, t, buf);
+  auto dma_tile = [&](int t, int buf, auto full_c) {
+    dma_half(K_{}, t, buf, full_c);
+    dma_half(V_{}, t, buf, full_c);
   };
   auto load_tile = [&](int64_t kv0) {
 #pragma unroll
@@ -222,7 +224,7 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnFwdPara
   const int nt = (int)((p.Nk + 63) / 64);
   {
     if (DMA) {
-      dma_tile(0, 0);
+      dma_tile(0, 0, std::false_type{});
     } else {
       load_tile(0);
       store_tile(0);
@@ -232,11 +234,12 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnFwdPara
 
   // LAST = the final (possibly ragged) tile, peeled so that the steady-state body carries neither the mask code nor its
   // register copies, and `has_next` is a compile-time constant in both
-  auto tile_body = [&](const int t, auto buf_c, auto last_c) {
+  // NEXT_FULL: tile t+1 is known not to be the last one (no ragged-row code in the steady-state bodies)
+  auto tile_body = [&](const int t, auto buf_c, auto last_c, auto next_full_c) {
     constexpr int buf = decltype(buf_c)::value;  // compile-time buffer: every LDS address is a fixed register + immediate
     constexpr bool has_next = !decltype(last_c)::value;
     if (has_next) {
-      if (DMA) dma_tile(t + 1, buf ^ 1);  // buf ^ 1 was last read in iteration t-1; every wave has passed its barrier
+      if (DMA) dma_tile(t + 1, buf ^ 1, next_full_c);  // buf ^ 1 was last read in iteration t-1; every wave has passed its barrier
       else load_tile((int64_t)(t + 1) * 64);
     }
 
@@ -361,16 +364,23 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnFwdPara
   {
     using B0 = std::integral_constant<int, 0>;
     using B1 = std::integral_constant<int, 1>;
+    using Y = std::true_type;
+    using N = std::false_type;
     int t = 0;
-    for (; t + 2 < nt; t += 2) {
-      tile_body(t, B0{}, std::false_type{});
-      tile_body(t + 1, B1{}, std::false_type{});
+    for (; t + 3 < nt; t += 2) {  // tiles t+1, t+2 <= nt-2: both full
+      tile_body(t, B0{}, N{}, Y{});
+      tile_body(t + 1, B1{}, N{}, Y{});
     }
-    if (t + 1 < nt) {
-      tile_body(t, B0{}, std::false_type{});
-      tile_body(t + 1, B1{}, std::true_type{});
+    const int left = nt - t;  // 1, 2 or 3 tiles, starting on buffer 0
+    if (left == 3) {
+      tile_body(t, B0{}, N{}, Y{});
+      tile_body(t + 1, B1{}, N{}, N{});
+      tile_body(t + 2, B0{}, Y{}, N{});
+    } else if (left == 2) {
+      tile_body(t, B0{}, N{}, N{});
+      tile_body(t + 1, B1{}, Y{}, N{});
     } else {
-      tile_body(t, B0{}, std::true_type{});
+      tile_body(t, B0{}, Y{}, N{});
     }
   }
 
