@@ -36,6 +36,20 @@ class HipLinear(nn.Linear):
         return y.view(*shp[:-1], self.out_features)
 
 
+def _proj_out(proj: "HipLinear", o: torch.Tensor, fuse) -> torch.Tensor:
+    """`proj(o)`, or — when the block passes `fuse = (resid, mod, gate_idx, T)` (inference, `proj` pristine) — the
+    block's `resid + gate * proj(o)` written by the GEMM's own epilogue: same fp32 arithmetic and rounding points as
+    `proj` followed by `gate_residual`, one HBM round trip of the activation less."""
+    if fuse is None:
+        return proj(o)
+    from lcv_hip.lib import LCV_EPI_GATE_RESIDUAL
+    resid, mod, gate_idx, T = fuse
+    B, N, C = resid.shape
+    out = ops.gemm_nt(o.reshape(B * N, -1), proj.weight, proj.bias, epilogue=LCV_EPI_GATE_RESIDUAL,
+                      resid=resid.reshape(B * N, C), mod=mod, gate_idx=gate_idx, rows_per_frame=max(N // T, 1))
+    return out.view(B, N, C)
+
+
 class LayerNorm_FP32(nn.LayerNorm):
     """fp32 LayerNorm returning the input dtype (upstream name kept for norm-tuning scripts)."""
 
@@ -120,25 +134,25 @@ class Attention(nn.Module):
         self.proj = HipLinear(dim, dim, bias=True, device=device, dtype=dtype)
         self.rope_3d = RotaryPositionalEmbedding(self.head_dim, cp_split_hw=cp_split_hw)
 
-    def forward(self, x, shape=None, num_cond_latents=None, return_kv=False):
+    def forward(self, x, shape=None, num_cond_latents=None, return_kv=False, fuse_residual=None):
         B, N, C = x.shape
         H, D = self.num_heads, self.head_dim
         qkv = self.qkv(x).view(B, N, 3, H, D)
         sp = getattr(self, "_sp", None)
         if sp is not None:
-            return self._forward_sequence_parallel(qkv, shape, num_cond_latents, sp)
+            return self._forward_sequence_parallel(qkv, shape, num_cond_latents, sp, fuse_residual)
         cs = self.rope_3d.table(shape, x.device)
         n_cond = 0
         if num_cond_latents is not None and num_cond_latents > 0:
             n_cond = num_cond_latents * (N // shape[0])
         o, kv = A.self_attention(qkv, self.q_norm.weight, self.k_norm.weight, cs, self.scale, n_cond,
                                  self.q_norm.eps, return_kv)
-        out = self.proj(o.view(B, N, C))
+        out = _proj_out(self.proj, o.view(B, N, C), fuse_residual)
         if return_kv:
             return out, kv
         return out
 
-    def _forward_sequence_parallel(self, qkv, shape, num_cond_latents, sp):
+    def _forward_sequence_parallel(self, qkv, shape, num_cond_latents, sp, fuse_residual=None):
         """Frame-sharded tokens: RoPE at GLOBAL positions, all-gather of K/V (post-norm, post-RoPE), local-Q x full-KV."""
         if torch.is_grad_enabled() and qkv.requires_grad:
             raise NotImplementedError("sequence-parallel attention is an inference path this round (dK/dV reduce-scatter next)")
@@ -151,9 +165,9 @@ class Attention(nn.Module):
                         q_scale=ops.log2_qscale(self.scale))
         k_full, v_full = sp.all_gather_kv(k.contiguous(), v.contiguous())
         o, _ = ops.attention(q, k_full, v_full, ops.LN2)
-        return self.proj(o.view(B, N, H * D))
+        return _proj_out(self.proj, o.view(B, N, H * D), fuse_residual)
 
-    def forward_with_kv_cache(self, x, shape=None, num_cond_latents=None, kv_cache=None):
+    def forward_with_kv_cache(self, x, shape=None, num_cond_latents=None, kv_cache=None, fuse_residual=None):
         """Denoise step over the noise tokens only; cached (post-norm, post-RoPE) cond K / V lead the keys."""
         B, N, C = x.shape
         H, D = self.num_heads, self.head_dim
@@ -165,7 +179,7 @@ class Attention(nn.Module):
         cs = self.rope_3d.table((T + t_c, Hh, Ww), x.device)
         o = A.cached_attention(qkv, k_c, v_c, self.q_norm.weight, self.k_norm.weight, cs, self.scale,
                                self.q_norm.eps)
-        return self.proj(o.view(B, N, C))
+        return _proj_out(self.proj, o.view(B, N, C), fuse_residual)
 
 
 class MultiHeadCrossAttention(nn.Module):
@@ -182,18 +196,20 @@ class MultiHeadCrossAttention(nn.Module):
         self.q_norm = RMSNorm_FP32(self.head_dim, eps=1e-6, device=device, dtype=dtype)
         self.k_norm = RMSNorm_FP32(self.head_dim, eps=1e-6, device=device, dtype=dtype)
 
-    def _process_cross_attn(self, x, cond, kv_seqlen):
+    def _process_cross_attn(self, x, cond, kv_seqlen, fuse_residual=None):
         B, N, C = x.shape
         H, D = self.num_heads, self.head_dim
         q = self.q_linear(x).view(B, N, H, D)
         kv = self.kv_linear(cond).view(1, -1, 2, H, D)
         o = A.cross_attention(q, kv, self.q_norm.weight, self.k_norm.weight, list(kv_seqlen), self.scale,
                               self.q_norm.eps)
-        return self.proj(o.view(B, N, C))
+        return _proj_out(self.proj, o.view(B, N, C), fuse_residual)
 
-    def forward(self, x, cond, kv_seqlen, num_cond_latents=None, shape=None):
+    def forward(self, x, cond, kv_seqlen, num_cond_latents=None, shape=None, fuse_residual=None):
         if num_cond_latents is None or num_cond_latents == 0:
-            return self._process_cross_attn(x, cond, kv_seqlen)
+            return self._process_cross_attn(x, cond, kv_seqlen, fuse_residual)
+        if fuse_residual is not None:
+            raise ValueError("fuse_residual is only offered without conditioning tokens")
         B, N, C = x.shape
         assert shape is not None, "SHOULD pass in the shape"
         n_cond = num_cond_latents * (N // shape[0])
@@ -228,7 +244,7 @@ class FeedForwardSwiGLU(nn.Module):
             self._w13_key = key
         return self._w13
 
-    def forward(self, x):
+    def forward(self, x, fuse_residual=None):
         shp = x.shape
         x2 = x.reshape(-1, shp[-1])
         w13 = None if torch.is_grad_enabled() else self.fused_w13()
@@ -236,6 +252,8 @@ class FeedForwardSwiGLU(nn.Module):
             h = A.swiglu_fused(x2, w13)
         else:
             h = A.swiglu(self.w1(x2), self.w3(x2))
+        if fuse_residual is not None:
+            return _proj_out(self.w2, h.view(*shp[:-1], -1), fuse_residual)
         return self.w2(h).view(*shp[:-1], self.dim)
 
 
@@ -333,21 +351,30 @@ class LongCatSingleStreamBlock(nn.Module):
         mod = self.adaLN_modulation(t)  # [B, T, 6C] fp32: shift_msa|scale_msa|gate_msa|shift_mlp|scale_mlp|gate_mlp
         x_m = A.adaln_modulate(x, mod, 0, 1, T, self.mod_norm_attn.eps)
         kv = None
+        # residual + gate folded into the output projection's GEMM epilogue: inference only, and only while the module
+        # whose forward receives the extra argument and the projection it swallows are pristine (hooks / LoRA keep working)
+        nograd = not torch.is_grad_enabled()
+        fa = (x, mod, 2, T) if (nograd and is_pristine(self.attn, Attention) and is_pristine(self.attn.proj, HipLinear)) else None
+        akw = {} if fa is None else {"fuse_residual": fa}
         if kv_cache is not None:
             x_s = self.attn.forward_with_kv_cache(x_m, shape=latent_shape, num_cond_latents=num_cond_latents,
-                                                  kv_cache=kv_cache)
+                                                  kv_cache=kv_cache, **akw)
         elif return_kv:
-            x_s, kv = self.attn(x_m, shape=latent_shape, num_cond_latents=num_cond_latents, return_kv=True)
+            x_s, kv = self.attn(x_m, shape=latent_shape, num_cond_latents=num_cond_latents, return_kv=True, **akw)
         else:
-            x_s = self.attn(x_m, shape=latent_shape, num_cond_latents=num_cond_latents)
-        x = A.gate_residual(x, x_s, mod, 2, T)
+            x_s = self.attn(x_m, shape=latent_shape, num_cond_latents=num_cond_latents, **akw)
+        x = x_s if fa is not None else A.gate_residual(x, x_s, mod, 2, T)
         if not skip_crs_attn:
             ncl = None if kv_cache is not None else num_cond_latents
-            x = A.gate_residual(x, self.cross_attn(self.pre_crs_attn_norm(x), y, y_seqlen, num_cond_latents=ncl,
-                                                   shape=latent_shape), None, 0, T)
+            fc = (x, None, 0, T) if (nograd and not ncl and is_pristine(self.cross_attn, MultiHeadCrossAttention)
+                                     and is_pristine(self.cross_attn.proj, HipLinear)) else None
+            ckw = {} if fc is None else {"fuse_residual": fc}
+            y_s = self.cross_attn(self.pre_crs_attn_norm(x), y, y_seqlen, num_cond_latents=ncl, shape=latent_shape, **ckw)
+            x = y_s if fc is not None else A.gate_residual(x, y_s, None, 0, T)
         x_m = A.adaln_modulate(x, mod, 3, 4, T, self.mod_norm_ffn.eps)
-        x_s = self.ffn(x_m)
-        x = A.gate_residual(x, x_s, mod, 5, T)
+        ff = (x, mod, 5, T) if (nograd and is_pristine(self.ffn, FeedForwardSwiGLU) and is_pristine(self.ffn.w2, HipLinear)) else None
+        x_s = self.ffn(x_m, **({} if ff is None else {"fuse_residual": ff}))
+        x = x_s if ff is not None else A.gate_residual(x, x_s, mod, 5, T)
         if return_kv:
             return x, kv
         return x

@@ -89,3 +89,40 @@ def test_dit_hooks_and_setattr_take_effect():
     assert rel_l2(run(), base) > 1e-3
     m.blocks[0].ffn.w1 = orig
     assert rel_l2(run(), base) == 0.0
+
+
+def test_fused_residual_epilogue_equals_unfused_and_yields_to_hooks():
+    """Inference folds `x + gate * proj(.)` into the projection GEMM's epilogue.  (1) it must equal the unfused path bit
+    for bit (same fp32 arithmetic and rounding points); (2) a hook / `setattr` / patched forward on the projection, or on
+    the module that owns it, must switch the fusion off and still take effect (run_lora_tta.py:137-140, 326-380)."""
+    from oracle import dit_oracle as orc
+    import torch.nn as nn
+    cfg = orc.small_config(hidden_size=256, depth=2, num_heads=2, caption_channels=64)
+    P = orc.make_params(cfg, seed=9, std=0.05)
+    m = _build(cfg, P)
+    hs, y, mask = _inputs(cfg, 2, 3, 8, 8, 16, [9, 16])
+    ts = torch.tensor([[0.0, 400.0, 400.0], [0.0, 650.0, 650.0]]).to(BF16)
+
+    def run(ncond):
+        with torch.no_grad():
+            return m(hs.cuda(), ts.cuda(), y.cuda(), mask.cuda(), num_cond_latents=ncond)
+
+    for ncond in (0, 1):
+        fused = run(ncond)
+        # no-op forward hooks on the three output projections: the fusion must step aside, the result must not change
+        hooks = []
+        for blk in m.blocks:
+            for lin in (blk.attn.proj, blk.cross_attn.proj, blk.ffn.w2):
+                hooks.append(lin.register_forward_hook(lambda mod, inp, out: out))
+        unfused = run(ncond)
+        for h in hooks:
+            h.remove()
+        assert torch.equal(fused, unfused), ncond
+    base = run(0)
+    h = m.blocks[1].attn.proj.register_forward_hook(lambda mod, inp, out: out * 1.5)
+    assert rel_l2(run(0), base) > 1e-3
+    h.remove()
+    h = m.blocks[0].ffn.register_forward_hook(lambda mod, inp, out: out * 0.5)      # hook on the owner module
+    assert rel_l2(run(0), base) > 1e-3
+    h.remove()
+    assert torch.equal(run(0), base)
