@@ -149,6 +149,45 @@ class DeltaCWrapper(_HookedWrapper):
         return pred + self.delta_out.view(1, -1, 1, 1, 1).to(pred.dtype)
 
 
+class FiLMAdapterWrapper(_HookedWrapper):
+    """Per-block-group additive corrections to the adaLN output [shift_msa | scale_msa | gate_msa | shift_mlp | scale_mlp |
+    gate_mlp] (delta_experiment/scripts/run_film_tta.py:78-176): forward hooks on every block's `adaLN_modulation`; the
+    gradient reaches the corrections through the modulation-table gradients of the adaLN / gate-residual kernels."""
+
+    def __init__(self, dit: nn.Module, num_groups: int = 4, hidden_size: int = 4096, film_mode: str = "full"):
+        super().__init__(dit)
+        dims = {"full": 6, "shift_scale": 4, "scale_only": 2}
+        if film_mode not in dims:
+            raise ValueError(f"Unknown film_mode: {film_mode}")
+        self.num_groups, self.num_blocks = num_groups, len(dit.blocks)
+        self.hidden_size, self.film_mode = hidden_size, film_mode
+        self.correction_dim = dims[film_mode] * hidden_size
+        self.corrections = nn.ParameterList([nn.Parameter(torch.zeros(self.correction_dim)) for _ in range(num_groups)])
+
+    def _get_group_idx(self, block_idx: int) -> int:
+        return block_idx * self.num_groups // self.num_blocks
+
+    def _expand_correction(self, corr: torch.Tensor) -> torch.Tensor:
+        C = self.hidden_size
+        if self.film_mode == "full":
+            return corr
+        z = torch.zeros(C, device=corr.device, dtype=corr.dtype)
+        if self.film_mode == "scale_only":   # [scale_msa, scale_mlp]
+            return torch.cat([z, corr[:C], z, z, corr[C:], z])
+        return torch.cat([corr[:C], corr[C:2 * C], z, corr[2 * C:3 * C], corr[3 * C:], z])  # shift_scale
+
+    def apply_to_dit(self):
+        self.remove_from_dit()
+        for i, blk in enumerate(self.dit.blocks):
+            corr = self.corrections[self._get_group_idx(i)]
+            self._hooks.append(blk.adaLN_modulation.register_forward_hook(
+                lambda _m, _i, out, corr=corr: out + self._expand_correction(corr).view(1, 1, -1).to(out.dtype)))
+
+    def reset_corrections(self):
+        for c in self.corrections:
+            c.data.zero_()
+
+
 def _optimize(wrapper: nn.Module, params: List[nn.Parameter], per_param_clip: bool, cond_latents, train_latents,
               prompt_embeds, prompt_mask, num_steps, lr, device, dtype, early_stopper, train_latents_variants):
     groups = [[p] for p in params] if per_param_clip else [params]
@@ -221,3 +260,15 @@ def optimize_delta_c(wrapper: DeltaCWrapper, cond_latents, train_latents, prompt
                                       prompt_mask, num_steps, lr, device, dtype, early_stopper, train_latents_variants)
     return {"losses": losses, "delta_norm": wrapper.delta_out.detach().norm().item(), "es_check_time": est,
             "early_stopping_info": es_state}
+
+
+def optimize_film_adapter(wrapper: FiLMAdapterWrapper, cond_latents, train_latents, prompt_embeds, prompt_mask,
+                          num_steps: int = 20, lr: float = 1e-3, device: str = "cuda", dtype: torch.dtype = torch.bfloat16,
+                          early_stopper: Optional[AnchoredEarlyStopper] = None,
+                          train_latents_variants: Optional[List[Dict]] = None) -> Dict:
+    """run_film_tta.py:266-341: AdamW(eps 1e-15) over all corrections, one global clip at 1.0."""
+    params = list(wrapper.corrections)
+    losses, est, es_state = _optimize(wrapper, params, False, cond_latents, train_latents, prompt_embeds, prompt_mask,
+                                      num_steps, lr, device, dtype, early_stopper, train_latents_variants)
+    return {"losses": losses, "correction_norm": sum(c.detach().norm().item() for c in wrapper.corrections),
+            "es_check_time": est, "early_stopping_info": es_state}

@@ -87,6 +87,19 @@ def test_delta_runners_parse_the_sbatch_flag_sets(rel, extra, check):
     assert check(args) and args.num_cond_frames == 14 and args.es_check_every == 5 and args.clip_gate_enabled is False
 
 
+def test_film_runner_parses_its_flags_and_has_no_clip_gate_group():
+    """run_film_tta.py:348-373 adds no CLIP-gate group and run_sweep.sbatch:586-591 passes none."""
+    m = _load_script("delta_experiment/scripts/run_film_tta.py")
+    common = [a for a in _COMMON if not a.startswith("--clip-gate")]
+    i = _COMMON.index("--clip-gate-threshold")
+    common = _COMMON[:i] + _COMMON[i + 2:]
+    a = m.build_parser().parse_args(common + ["--film-steps", "20", "--film-lr", "1e-3", "--num-groups", "4", "--film-mode",
+                                              "shift_scale"])
+    assert a.film_mode == "shift_scale" and a.num_groups == 4 and not hasattr(a, "clip_gate_enabled")
+    with pytest.raises(SystemExit):
+        m.build_parser().parse_args(common + ["--clip-gate-enabled"])
+
+
 def test_baseline_runner_parses_the_reference_flags():
     """baseline_experiment/scripts/run_baseline.py:235-262."""
     m = _load_script("baseline_experiment/scripts/run_baseline.py")
