@@ -287,7 +287,8 @@ def main(argv=None):
                    "num_failed": len(merged) - len(ok), "avg_train_time": mean("train_time"),
                    "avg_clip_gate_eval_time": 0, "avg_es_check_time": mean("es_check_time"),
                    "avg_gen_time": mean("gen_time"), "avg_total_time": mean("total_time"),
-                   "avg_final_loss": float(np.mean([r["final_loss"] for r in ok if r.get("final_loss") is not None])) if ok else 0,
+                   "avg_final_loss": (lambda v: float(np.mean(v)) if v else None)(
+                       [r["final_loss"] for r in ok if r.get("final_loss") is not None]),
                    "clip_gate_enabled": False, "clip_gate_stats": {"skip_rate": 0.0, "num_skipped": 0, "num_scored": 0},
                    "results": merged}
         dp.write_checkpoint(args.output_dir, dp.contiguous_next_idx(merged), merged)

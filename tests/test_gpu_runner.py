@@ -81,3 +81,17 @@ def test_baseline_runner_end_to_end(tmp_path):
     assert "metrics" in s and "results" not in s and s["num_successful"] == 2 and s["num_frames_total"] == 13
     assert s["timing"]["per_video_inference_s"]["mean"] is not None
     assert (out / "per_video_metrics.csv").read_text().splitlines()[0].startswith("index,filename,caption,psnr")
+
+
+def test_no_tta_control_num_steps_zero(tmp_path):
+    """The reference's no-TTA control is the TTA runner with `num_steps: 0` (sweep_experiment/configs/ucf101_no_tta.yaml:8-15):
+    the adapters stay at their zero-effect initialisation, the run succeeds, final_loss is null."""
+    spec = importlib.util.spec_from_file_location("run_lora_tta_amd", RUNNER)
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    out = tmp_path / "ctl"
+    m.main(["--checkpoint-dir", "synthetic:2:256:64", "--data-dir", "synthetic:1", "--output-dir", str(out), "--num-cond-frames", "5",
+            "--num-frames", "13", "--gen-start-frame", "40", "--tta-total-frames", "33", "--tta-context-frames", "9", "--num-steps", "0",
+            "--es-disable", "--num-inference-steps", "2"])
+    s = json.loads((out / "summary.json").read_text())
+    r = s["results"][0]
+    assert s["num_successful"] == 1 and r["num_train_steps"] == 0 and r["final_loss"] is None and r["gen_time"] > 0
