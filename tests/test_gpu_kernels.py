@@ -281,3 +281,37 @@ def test_denoise_glue_and_loss_pieces():
     assert abs(loss.item() - ref.item()) < 1e-5 * max(1.0, ref.item())
     gref = torch.zeros_like(pred); gref[:, :, 2:] = 2 * (pred[:, :, 2:] - tgt) / tgt.numel()
     assert torch.allclose(dpred.cpu(), gref, atol=1e-7, rtol=1e-5)
+
+
+def test_gemm_8phase_race_screen_shapes_and_epilogues(monkeypatch):
+    """A synchronisation edit makes a new schedule (cdna_hip_programming.md: "screen it for races over many runs at several
+    sizes"): the 8-phase and the persistent 8-phase kernels against the one-barrier kernel, bit for bit, over even / odd
+    K-tile counts (the tail of the LDS-DMA pipeline differs), with and without the rank-r K tile, ragged M / N edges, fewer
+    and more tiles than CUs, and every fused epilogue."""
+    ops = _ops()
+    from lcv_hip.lib import LCV_EPI_GATE_RESIDUAL, LCV_EPI_GELU_TANH, LCV_EPI_NONE, LCV_EPI_SILU, LCV_EPI_SWIGLU
+    g = torch.Generator().manual_seed(123)
+    shapes = [(2048, 1024, 128, 0), (2049, 1030, 192, 0), (3000, 2050, 1088, 64), (256 * 19 + 7, 256 * 15, 256, 0),
+              (256 * 30, 256 * 10 + 64, 320, 64), (4100, 1024, 2048, 0)]
+    for (M, N, K, K2) in shapes:
+        a = (torch.randn(M, K, generator=g)).to(BF16).to(DEV); w = (torch.randn(N, K, generator=g) * 0.05).to(BF16).to(DEV)
+        b = torch.randn(N, generator=g).to(BF16).to(DEV)
+        a2 = torch.randn(M, K2, generator=g).to(BF16).to(DEV) if K2 else None
+        w2 = (torch.randn(N, K2, generator=g) * 0.05).to(BF16).to(DEV) if K2 else None
+        resid = torch.randn(M, N, generator=g).to(BF16).to(DEV)
+        mod = torch.randn(1, 3, 6 * N, generator=g).to(DEV)
+        cases = [dict(epilogue=LCV_EPI_NONE), dict(epilogue=LCV_EPI_NONE, out_f32=True), dict(epilogue=LCV_EPI_GELU_TANH),
+                 dict(epilogue=LCV_EPI_SILU),
+                 dict(epilogue=LCV_EPI_GATE_RESIDUAL, resid=resid, mod=mod, gate_idx=2, rows_per_frame=(M + 2) // 3),
+                 dict(epilogue=LCV_EPI_GATE_RESIDUAL, resid=resid)]
+        if N % 64 == 0:
+            cases.append(dict(epilogue=LCV_EPI_SWIGLU))
+        for kw in cases:
+            bias = None if kw["epilogue"] == LCV_EPI_SWIGLU else b
+            monkeypatch.setenv("LCV_GEMM_TILE", "6")
+            ref = ops.gemm_nt(a, w, bias, a2=a2, w2=w2, **kw)
+            for tile in ("8", "9"):
+                monkeypatch.setenv("LCV_GEMM_TILE", tile)
+                for _ in range(2):
+                    got = ops.gemm_nt(a, w, bias, a2=a2, w2=w2, **kw)
+                    assert torch.equal(got, ref), (M, N, K, K2, kw["epilogue"], tile)
