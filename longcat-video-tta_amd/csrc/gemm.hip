@@ -34,7 +34,7 @@ struct GemmParams {
   const bf16_t* resid;
   const float* gate;  // mod + gate_off
   int64_t rows_per_frame, mod_stride;
-  int tiles_m, tiles_n;
+  int tiles_m, tiles_n, group_m;
   // implicit-GEMM convolution mode (channels-last activations [B,Tin,Hin,Win,Cin], rows m = output pixels):
   // K tiles run over (tap, 64-channel chunk); out-of-range taps read a zero page.
   int cv_T, cv_H, cv_W;        // output extent (rows m = ((b*T + t)*H + h)*W + w)
@@ -66,11 +66,11 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
 }
 
 // Workgroup id -> output tile.  Ids that share an XCD (id % 8, observed round-robin dealing; speed only) get a contiguous run
-// of the tile sequence, and the sequence itself is "grouped": GROUP_M consecutive tile rows are walked column by column,
-// so the ~32 workgroups resident on one XCD cover an 8 x 4 block of tiles and share 8 A panels + 4 W panels in that
-// XCD's L2 instead of 32 A panels + 1 W panel.
+// of the tile sequence, and the sequence itself is "grouped": GROUP_M (p.group_m) consecutive tile rows are walked column by
+// column, so the ~32 workgroups resident on one XCD cover a GROUP_M x (32 / GROUP_M) block of tiles and share that many A
+// and W panels in that XCD's L2 instead of 32 A panels + 1 W panel.
 __device__ __forceinline__ void gemm_tile_coords(const GemmParams& p, int orig, int& tm, int& tn) {
-  constexpr int GROUP_M = 8;
+  const int GROUP_M = p.group_m;
   const int nwg = p.tiles_m * p.tiles_n;
   const int xcd = orig & 7;
   const int q = nwg >> 3, r8 = nwg & 7;
@@ -822,6 +822,9 @@ __global__ __launch_bounds__(512) void gemm8p_nt_kernel(const GemmParams p) {
 template <int EPI, bool PERSIST>
 static int launch_gemm8p(GemmParams& p, hipStream_t s) {
   p.tiles_m = (int)((p.M + 255) / 256);
+  // tile rows per group of the tile order (A/B knob LCV_GEMM_GROUP_M): 6 measured best for the persistent kernel at the K3
+  // projection shapes (4, 6, 8, 16 -> 1267, 1285, 1240, 1172 TF/s on the qkv GEMM, in one process)
+  { const char* ge = getenv("LCV_GEMM_GROUP_M"); p.group_m = ge ? atoi(ge) : 6; if (p.group_m < 1) p.group_m = 6; }
   p.tiles_n = (int)((p.N + 255) / 256);
   const size_t lds = 2 * 65536;
   auto kern = gemm8p_nt_kernel<EPI, PERSIST>;
@@ -844,6 +847,7 @@ template <int BM, int BN, int WR, int WC, int EPI, bool CONV>
 static int launch_gemm16(GemmParams& p, hipStream_t s) {
   using Cfg = GemmCfg<BM, BN, WR, WC>;
   p.tiles_m = (int)((p.M + BM - 1) / BM);
+  p.group_m = 8;
   p.tiles_n = (int)((p.N + BN - 1) / BN);
   const size_t lds = 2 * Cfg::STAGE_BYTES;
   auto kern = gemm16_nt_kernel<BM, BN, WR, WC, EPI, CONV>;
@@ -864,6 +868,7 @@ template <int BM, int BN, int WR, int WC, int EPI, bool CONV>
 static int launch_gemm(GemmParams& p, hipStream_t s) {
   using Cfg = GemmCfg<BM, BN, WR, WC>;
   p.tiles_m = (int)((p.M + BM - 1) / BM);
+  p.group_m = 8;
   p.tiles_n = (int)((p.N + BN - 1) / BN);
   const size_t lds = 2 * Cfg::STAGE_BYTES;
   auto kern = gemm_nt_kernel<BM, BN, WR, WC, EPI, CONV>;

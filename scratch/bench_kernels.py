@@ -34,6 +34,14 @@ if which in ("attn_unit",):
         ms=timeit(lambda: ops.attention(q_pre,qkv[:,:,1],qkv[:,:,2],math.log(2.0),out=o2), n=3, warm=1)
         print(f"attn unit    N={N}: {ms:.2f} ms  {fl/ms/1e9:.1f} TF/s", flush=True)
         d=(o.float()-o2.float()); print("rel_l2 unit vs general:", (d.norm()/o.float().norm()).item(), "max abs", d.abs().max().item())
+if which in ("gemm_group",):
+    for (M,N,K,name) in ((46800,12288,4096,"qkv"),(46800,4096,4096,"proj"),(46800,22016,4096,"w13"),(46800,4096,11008,"w2")):
+        a=torch.randn(M,K,device=dev,dtype=bf); w=torch.randn(N,K,device=dev,dtype=bf)*0.02; b=torch.randn(N,device=dev,dtype=bf)
+        for gm in ("4","8","4","8","6","8","16"):
+            os.environ["LCV_GEMM_GROUP_M"]=gm
+            ms=timeit(lambda: ops.gemm_nt(a,w,b), n=5, warm=2)
+            print(f"gemm group_m={gm} {name}: {ms:.2f} ms  {2*M*N*K/ms/1e9:.1f} TF/s", flush=True)
+        del a,w
 if which in ("all","gemm"):
     for (M,N,K,name) in ((46800,12288,4096,"qkv"),(46800,4096,4096,"proj"),(46800,22016,4096,"w13"),(46800,4096,11008,"w2")):
         a=torch.randn(M,K,device=dev,dtype=bf); w=torch.randn(N,K,device=dev,dtype=bf)*0.02; b=torch.randn(N,device=dev,dtype=bf)
