@@ -101,8 +101,10 @@ int lcv_qknorm_rope_fwd(const void* q_in, const void* k_in, const void* v_in,
                         int64_t kv_sb, int64_t kv_sn,       /* k_out/v_out strides */
                         int64_t pos_off, float eps, float q_scale, void* stream);
 /* Backward: given dq_out, dk_out (same addressing as q_out/k_out) and the
- * pre-norm q_in/k_in, writes dq_in, dk_in (strides din_*); q_scale as in the forward.  The norm
- * weights are frozen on this path (qk_norm tuning is out of scope). */
+ * pre-norm q_in/k_in, writes dq_in, dk_in (strides din_*); q_scale as in the forward.  dwq / dwk
+ * (nullable, fp32 [128], ACCUMULATED into by atomics - zero them first) receive the gradients of the
+ * two norm weights (norm-weight tuning, delta_experiment/scripts/run_norm_tune_tta.py:87-98); the dq
+ * share is w.r.t. the weight as it enters the forward, i.e. it carries q_scale. */
 int lcv_qknorm_rope_bwd(const void* q_in, const void* k_in,
                         const void* dq_out, const void* dk_out,
                         void* dq_in, void* dk_in,
@@ -112,7 +114,7 @@ int lcv_qknorm_rope_bwd(const void* q_in, const void* k_in,
                         int64_t q_sb, int64_t q_sn,
                         int64_t kv_sb, int64_t kv_sn,
                         int64_t din_sb, int64_t din_sn,
-                        int64_t pos_off, float eps, float q_scale, void* stream);
+                        int64_t pos_off, float eps, float q_scale, float* dwq, float* dwk, void* stream);
 
 /* ---- flash attention (dense, non-causal, head_dim 128, bf16, fp32 acc) */
 /* o[b,n,h,:] = softmax(q k^T * scale) v ; q: Nq rows, k/v: Nk rows.

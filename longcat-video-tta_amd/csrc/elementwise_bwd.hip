@@ -171,7 +171,7 @@ extern "C" int lcv_gate_residual_bwd(const void* y, const float* mod, const void
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void norm_rope_bwd_vec(const bf16_t* xin, const bf16_t* dout, bf16_t* dxin,
                                                   const float (&w)[8], const float (&cs)[8], bool do_rope,
-                                                  float eps, float out_scale) {
+                                                  float eps, float out_scale, float (&dwacc)[8], bool want_dw) {
   float x[8], d[8];
   unpack8(*reinterpret_cast<const u16x8*>(xin), x);
   unpack8(*reinterpret_cast<const u16x8*>(dout), d);
@@ -199,6 +199,10 @@ __device__ __forceinline__ void norm_rope_bwd_vec(const bf16_t* xin, const bf16_
     }
     dn[2 * i] = d0 * w[2 * i];
     dn[2 * i + 1] = d1 * w[2 * i + 1];
+    if (want_dw) {  // y = rope(n * w): dw += rope^T(dout) * n (norm-weight tuning, run_norm_tune_tta.py:87-98)
+      dwacc[2 * i] += d0 * (x[2 * i] * r);
+      dwacc[2 * i + 1] += d1 * (x[2 * i + 1] * r);
+    }
   }
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(
     const bf16_t* __restrict__ dk_out, bf16_t* __restrict__ dq_in, bf16_t* __restrict__ dk_in,
     const bf16_t* __restrict__ wq, const bf16_t* __restrict__ wk, const float* __restrict__ cs_tab, int H,
     int64_t in_sb, int64_t in_sn, int64_t q_sb, int64_t q_sn, int64_t kv_sb, int64_t kv_sn, int64_t din_sb,
-    int64_t din_sn, int64_t pos_off, float eps, float q_scale) {
+    int64_t din_sn, int64_t pos_off, float eps, float q_scale, float* __restrict__ dwq, float* __restrict__ dwk) {
   const int64_t n = blockIdx.x, b = blockIdx.y;
   const int sub = threadIdx.x & 15;
   const int hl = threadIdx.x >> 4;
@@ -237,16 +241,30 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(
   float wqf[8], wkf[8];
   unpack8(*reinterpret_cast<const u16x8*>(wq + sub * 8), wqf);
   unpack8(*reinterpret_cast<const u16x8*>(wk + sub * 8), wkf);
+  float dwq_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dwk_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (int h0 = 0; h0 < H; h0 += 16) {
     const int h = h0 + hl;
     if (h >= H) continue;
     const int64_t off = (int64_t)h * 128 + sub * 8;
     if (q_in)
       norm_rope_bwd_vec(q_in + b * in_sb + n * in_sn + off, dq_out + b * q_sb + n * q_sn + off,
-                        dq_in + b * din_sb + n * din_sn + off, wqf, cs, do_rope, eps, q_scale);
+                        dq_in + b * din_sb + n * din_sn + off, wqf, cs, do_rope, eps, q_scale, dwq_acc, dwq != nullptr);
     if (k_in)
       norm_rope_bwd_vec(k_in + b * in_sb + n * in_sn + off, dk_out + b * kv_sb + n * kv_sn + off,
-                        dk_in + b * din_sb + n * din_sn + off, wkf, cs, do_rope, eps, 1.0f);
+                        dk_in + b * din_sb + n * din_sn + off, wkf, cs, do_rope, eps, 1.0f, dwk_acc, dwk != nullptr);
+  }
+  // norm-weight gradients (only when asked for): sum over this wave's 4 heads-in-flight, then one atomic per (wave, dim)
+  if (dwq != nullptr || dwk != nullptr) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float a = dwq_acc[i], c = dwk_acc[i];
+      a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+      c += __shfl_xor(c, 16, 64); c += __shfl_xor(c, 32, 64);
+      if ((threadIdx.x & 63) < 16) {
+        if (dwq != nullptr && q_in) atomicAdd(dwq + sub * 8 + i, a);
+        if (dwk != nullptr && k_in) atomicAdd(dwk + sub * 8 + i, c);
+      }
+    }
   }
 }
 
@@ -254,7 +272,7 @@ extern "C" int lcv_qknorm_rope_bwd(const void* q_in, const void* k_in, const voi
                                    void* dq_in, void* dk_in, const void* wq, const void* wk, const void* cs,
                                    int64_t B, int64_t N, int64_t H, int64_t in_sb, int64_t in_sn, int64_t q_sb,
                                    int64_t q_sn, int64_t kv_sb, int64_t kv_sn, int64_t din_sb, int64_t din_sn,
-                                   int64_t pos_off, float eps, float q_scale, void* stream) {
+                                   int64_t pos_off, float eps, float q_scale, float* dwq, float* dwk, void* stream) {
   LCV_CHECK_ARG((q_in || k_in) && wq && wk, "qknorm_rope_bwd: null pointer");
   LCV_CHECK_ARG(!q_in || (dq_out && dq_in), "qknorm_rope_bwd: q gradients missing");
   LCV_CHECK_ARG(!k_in || (dk_out && dk_in), "qknorm_rope_bwd: k gradients missing");
@@ -263,7 +281,7 @@ extern "C" int lcv_qknorm_rope_bwd(const void* q_in, const void* k_in, const voi
   hipLaunchKernelGGL(qknorm_rope_bwd_kernel, dim3((unsigned)N, (unsigned)B), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)q_in, (const bf16_t*)k_in, (const bf16_t*)dq_out, (const bf16_t*)dk_out,
                      (bf16_t*)dq_in, (bf16_t*)dk_in, (const bf16_t*)wq, (const bf16_t*)wk, (const float*)cs,
-                     (int)H, in_sb, in_sn, q_sb, q_sn, kv_sb, kv_sn, din_sb, din_sn, pos_off, eps, q_scale);
+                     (int)H, in_sb, in_sn, q_sb, q_sn, kv_sb, kv_sn, din_sb, din_sn, pos_off, eps, q_scale, dwq, dwk);
   LCV_LAUNCH_CHECK("qknorm_rope_bwd");
   return LCV_OK;
 }

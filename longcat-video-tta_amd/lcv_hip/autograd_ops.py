@@ -243,8 +243,7 @@ class _SelfAttentionFn(torch.autograd.Function):
     def backward(ctx, do):
         qkv, qk, o, wq, wk, cs, *lses = ctx.saved_tensors
         scale, n_cond, eps = ctx.args
-        if wq.requires_grad or wk.requires_grad:
-            raise LcvError("self_attention: q/k norm weight gradients are not implemented (qk_norm tuning is out of scope)")
+        want_dw = wq.requires_grad or wk.requires_grad   # norm-weight tuning (run_norm_tune_tta.py, --norm-target qk_norm)
         B, N, _, H, D = qkv.shape
         do = do.contiguous()
         dqkv_r = torch.zeros((B, N, 3, H, D), dtype=BF16, device=qkv.device)  # grads w.r.t. roped q,k and v
@@ -260,10 +259,13 @@ class _SelfAttentionFn(torch.autograd.Function):
         else:
             ops.attention_bwd(q, k, v, o, do, lses[0], dq, dk, dv, ops.LN2, accumulate_kv=False)
         dqkv = torch.empty_like(qkv)
+        dwq = torch.zeros(D, dtype=torch.float32, device=qkv.device) if want_dw else None
+        dwk = torch.zeros(D, dtype=torch.float32, device=qkv.device) if want_dw else None
         ops.qknorm_rope_bwd(qkv[:, :, 0], qkv[:, :, 1], dq, dk, dqkv[:, :, 0], dqkv[:, :, 1], wq, wk, cs, 0, eps,
-                            q_scale=ops.log2_qscale(scale))
+                            q_scale=ops.log2_qscale(scale), dwq=dwq, dwk=dwk)
         dqkv[:, :, 2].copy_(dv)
-        return dqkv, None, None, None, None, None, None
+        return (dqkv, dwq.to(wq.dtype) if (want_dw and wq.requires_grad) else None,
+                dwk.to(wk.dtype) if (want_dw and wk.requires_grad) else None, None, None, None, None)
 
 
 def self_attention(qkv, wq, wk, cs, scale, n_cond, eps, return_kv=False):
@@ -322,8 +324,7 @@ class _CrossAttentionFn(torch.autograd.Function):
     def backward(ctx, do):
         q_raw, kv_raw, qn, kn, o, wq, wk, *lses = ctx.saved_tensors
         seqlens, scale, eps = ctx.args
-        if wq.requires_grad or wk.requires_grad:
-            raise LcvError("cross_attention: q/k norm weight gradients are not implemented")
+        want_dw = wq.requires_grad or wk.requires_grad
         B, N, H, D = q_raw.shape
         L = kv_raw.shape[1]
         do = do.contiguous()
@@ -337,11 +338,14 @@ class _CrossAttentionFn(torch.autograd.Function):
                               accumulate_kv=False)
             off += Lb
         dq_raw = torch.empty_like(q_raw)
-        ops.qknorm_rope_bwd(q_raw, None, dqn, None, dq_raw, None, wq, wk, None, 0, eps)
+        dwq = torch.zeros(D, dtype=torch.float32, device=q_raw.device) if want_dw else None
+        dwk = torch.zeros(D, dtype=torch.float32, device=q_raw.device) if want_dw else None
+        ops.qknorm_rope_bwd(q_raw, None, dqn, None, dq_raw, None, wq, wk, None, 0, eps, dwq=dwq)
         dkv_raw = torch.empty_like(kv_raw)
-        ops.qknorm_rope_bwd(None, kv_raw[:, :, 0], None, dkv[:, :, 0], None, dkv_raw[:, :, 0], wq, wk, None, 0, eps)
+        ops.qknorm_rope_bwd(None, kv_raw[:, :, 0], None, dkv[:, :, 0], None, dkv_raw[:, :, 0], wq, wk, None, 0, eps, dwk=dwk)
         dkv_raw[:, :, 1].copy_(dkv[:, :, 1])
-        return dq_raw, dkv_raw, None, None, None, None, None
+        return (dq_raw, dkv_raw, dwq.to(wq.dtype) if (want_dw and wq.requires_grad) else None,
+                dwk.to(wk.dtype) if (want_dw and wk.requires_grad) else None, None, None, None)
 
 
 def cross_attention(q, kv, wq, wk, seqlens: List[int], scale, eps):

@@ -301,7 +301,9 @@ def gate_residual_bwd(y, mod, dout, gate_idx, T, need_dmod=False):
     return dy, dmod
 
 
-def qknorm_rope_bwd(q_in, k_in, dq_out, dk_out, dq_in, dk_in, wq, wk, cs, pos_off=0, eps=1e-6, q_scale=1.0):
+def qknorm_rope_bwd(q_in, k_in, dq_out, dk_out, dq_in, dk_in, wq, wk, cs, pos_off=0, eps=1e-6, q_scale=1.0,
+                    dwq: Optional[torch.Tensor] = None, dwk: Optional[torch.Tensor] = None):
+    """dwq / dwk: optional fp32 [128] accumulators (zeroed by the caller) for the norm-weight gradients."""
     ref = q_in if q_in is not None else k_in
     B, N, H, D = ref.shape
     go = dq_out if dq_out is not None else dk_out
@@ -312,7 +314,7 @@ def qknorm_rope_bwd(q_in, k_in, dq_out, dk_out, dq_in, dk_in, wq, wk, cs, pos_of
             raise _lib.LcvError("qknorm_rope_bwd: (H, D) must be contiguous")
     call("lcv_qknorm_rope_bwd", _ptr(q_in), _ptr(k_in), _ptr(dq_out), _ptr(dk_out), _ptr(dq_in), _ptr(dk_in),
          _ptr(wq), _ptr(wk), _ptr(cs), B, N, H, ref.stride(0), ref.stride(1), go.stride(0), go.stride(1),
-         gk.stride(0), gk.stride(1), gi.stride(0), gi.stride(1), pos_off, eps, q_scale, _stream())
+         gk.stride(0), gk.stride(1), gi.stride(0), gi.stride(1), pos_off, eps, q_scale, _ptr(dwq), _ptr(dwk), _stream())
 
 
 def attention_bwd(q, k, v, o, do, lse, dq, dk, dv, scale, accumulate_kv=False):

@@ -272,3 +272,71 @@ def optimize_film_adapter(wrapper: FiLMAdapterWrapper, cond_latents, train_laten
                                       num_steps, lr, device, dtype, early_stopper, train_latents_variants)
     return {"losses": losses, "correction_norm": sum(c.detach().norm().item() for c in wrapper.corrections),
             "es_check_time": est, "early_stopping_info": es_state}
+
+
+# --------------------------------------------------------------------------- norm tuning (run_norm_tune_tta.py)
+def collect_norm_params(dit: nn.Module, norm_target: str) -> List[nn.Parameter]:
+    """The affine norm parameters the reference unfreezes (run_norm_tune_tta.py:74-98): the cross-attention pre-norm
+    (weight, bias) and / or the four q/k RMS-norm weights of every block, in the reference's order."""
+    if norm_target not in ("cross_attn_norm", "qk_norm", "all_norm"):
+        raise ValueError(f"Unknown norm_target: {norm_target}")
+    params = []
+    for blk in dit.blocks:
+        if norm_target in ("cross_attn_norm", "all_norm"):
+            n = blk.pre_crs_attn_norm
+            if getattr(n, "weight", None) is not None:
+                params.append(n.weight)
+            if getattr(n, "bias", None) is not None:
+                params.append(n.bias)
+        if norm_target in ("qk_norm", "all_norm"):
+            for mod in (blk.attn.q_norm, blk.attn.k_norm, blk.cross_attn.q_norm, blk.cross_attn.k_norm):
+                if getattr(mod, "weight", None) is not None:
+                    params.append(mod.weight)
+    return params
+
+
+class NormTuneForward(nn.Module):
+    """Thin wrapper: the DiT itself carries the unfrozen norm parameters (run_norm_tune_tta.py:116-208); `apply_to_dit` /
+    `remove_from_dit` exist so the shared runner loop can treat it like the hook-based wrappers (the tuned weights are in
+    the modules already; `restore()` puts the per-job originals back for the next video)."""
+
+    def __init__(self, dit: nn.Module, norm_target: str = "all_norm"):
+        super().__init__()
+        self.dit = dit
+        for p in dit.parameters():
+            p.requires_grad = False
+        self.norm_params = collect_norm_params(dit, norm_target)
+        for p in self.norm_params:
+            p.requires_grad = True
+        self._orig = [p.data.clone() for p in self.norm_params]
+
+    @property
+    def config(self):
+        return self.dit.config
+
+    def apply_to_dit(self):
+        pass
+
+    def remove_from_dit(self):
+        pass
+
+    def restore(self):
+        for p, o in zip(self.norm_params, self._orig):
+            p.data.copy_(o)
+            p.requires_grad = False
+            p.grad = None
+
+    def forward(self, hidden_states, timestep, encoder_hidden_states, encoder_attention_mask=None, num_cond_latents=0, **kw):
+        return self.dit(hidden_states=hidden_states, timestep=timestep, encoder_hidden_states=encoder_hidden_states,
+                        encoder_attention_mask=encoder_attention_mask, num_cond_latents=num_cond_latents)
+
+
+def optimize_norm_params(wrapper: NormTuneForward, cond_latents, train_latents, prompt_embeds, prompt_mask, num_steps: int = 20,
+                         lr: float = 1e-3, device: str = "cuda", dtype: torch.dtype = torch.bfloat16,
+                         early_stopper: Optional[AnchoredEarlyStopper] = None,
+                         train_latents_variants: Optional[List[Dict]] = None) -> Dict:
+    """run_norm_tune_tta.py:215-283: AdamW(eps 1e-15) over the norm parameters (bf16, like the module), global clip 1.0."""
+    losses, est, es_state = _optimize(wrapper, wrapper.norm_params, False, cond_latents, train_latents, prompt_embeds,
+                                      prompt_mask, num_steps, lr, device, dtype, early_stopper, train_latents_variants)
+    drift = sum((p.detach().float() - o.float()).norm().item() for p, o in zip(wrapper.norm_params, wrapper._orig))
+    return {"losses": losses, "norm_param_drift": drift, "es_check_time": est, "early_stopping_info": es_state}

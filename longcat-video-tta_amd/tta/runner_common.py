@@ -154,7 +154,7 @@ def clip_gate_summary(args) -> Dict:
 
 
 def run_delta_method(args, method: str, make_wrapper: Callable, optimize_fn: Callable, params_of: Callable,
-                     result_extra: Callable, summary_head: Dict, file_suffix: str):
+                     result_extra: Callable, summary_head: Dict, file_suffix: str, cleanup: Callable = None):
     """The per-video loop of the delta runners: fresh wrapper -> (anchored early stopping) -> optimise on the conditioning
     window -> continuation with the wrapper's hooks installed -> checkpoint after every video -> summary."""
     C.normalize_tta_frame_args(args)
@@ -181,6 +181,7 @@ def run_delta_method(args, method: str, make_wrapper: Callable, optimize_fn: Cal
 
     for idx in my_idx:
         e = entries[idx]
+        wrapper = None
         try:
             torch.manual_seed(dp.seed_for_video(args.seed, idx))
             blob = load_entry(e, args, dit, device)
@@ -226,6 +227,9 @@ def run_delta_method(args, method: str, make_wrapper: Callable, optimize_fn: Cal
             traceback.print_exc()
             all_results.append({"idx": idx, "video_name": e["name"], "video_path": e["path"], "error": str(ex),
                                 "success": False})
+        finally:
+            if cleanup is not None and wrapper is not None:
+                cleanup(wrapper)   # e.g. norm tuning: put the job's original weights back before the next video
         dp.write_checkpoint(args.output_dir, idx + world, all_results, rank=rank if world > 1 else None)
 
     merged = dp.gather_results(all_results) if world > 1 else dp.merge_results([all_results])

@@ -382,3 +382,43 @@ def test_series25_delta_a_equals_delta_b_one_group_and_film_grads():
     for c in wf.corrections:
         assert c.grad is not None and torch.isfinite(c.grad).all() and c.grad.abs().max() > 0
     assert not any(b.adaLN_modulation._forward_hooks for b in m.blocks)
+
+
+def test_qk_norm_weight_gradients():
+    """Norm-weight tuning (run_norm_tune_tta.py, --norm-target qk_norm / cross_attn_norm): gradients of the q/k RMS-norm
+    weights (self- and cross-attention) and of the cross-attention pre-norm affine, against torch autograd over the fp32
+    oracle with the same weights as leaves."""
+    from oracle import dit_oracle as orc
+    from tta.delta import collect_norm_params
+    from tta.flow_matching import fm_mse_loss
+    m, cfg, P = _small_dit()
+    params = collect_norm_params(m, "all_norm")
+    assert len(params) == len(m.blocks) * 6
+    for p_ in m.parameters():
+        p_.requires_grad = False
+    for p_ in params:
+        p_.requires_grad = True
+    m.train()
+    B, T, H, W, L, ncond = 1, 3, 8, 8, 16, 1
+    hs = _randn(B, 16, T, H, W, seed=60); y = _randn(B, 1, L, 64, seed=61)
+    mask = torch.zeros(B, L, dtype=torch.int64); mask[:, :11] = 1
+    ts = torch.zeros(B, T); ts[:, ncond:] = 600.0
+    eps = _randn(B, 16, T - ncond, H, W, seed=62); x0 = _randn(B, 16, T - ncond, H, W, seed=63)
+    pred = m(hs.to(DEV), ts.to(BF16).to(DEV), y.to(DEV), mask.to(DEV), num_cond_latents=ncond)
+    fm_mse_loss(pred, eps.to(DEV), x0.to(DEV), ncond).backward()
+    Pf = {k: v.float() for k, v in P.items()}
+    names = []
+    for i in range(len(m.blocks)):
+        names += [f"blocks.{i}.pre_crs_attn_norm.weight", f"blocks.{i}.pre_crs_attn_norm.bias", f"blocks.{i}.attn.q_norm.weight",
+                  f"blocks.{i}.attn.k_norm.weight", f"blocks.{i}.cross_attn.q_norm.weight", f"blocks.{i}.cross_attn.k_norm.weight"]
+    for n in names:
+        Pf[n] = Pf[n].clone().requires_grad_(True)
+    ref = orc.dit_forward(Pf, cfg, hs, ts.to(BF16), y, mask, ncond, bf16=False)
+    torch.nn.functional.mse_loss(ref[:, :, ncond:], (eps - x0).float()).backward()
+    worst = 0.0
+    for n, p_ in zip(names, params):
+        assert p_.grad is not None, n
+        e = rel_l2(p_.grad, Pf[n].grad)
+        worst = max(worst, e)
+        assert e < 6e-2, (n, e)
+    print("norm-weight gradient rel-L2 (max over 12 tensors):", worst)

@@ -50,6 +50,8 @@ def _run(rel, argv):
     ("delta_experiment/scripts/run_delta_c.py", "delta_c", ["--delta-steps", "4", "--delta-lr", "1e-2"], "delta_norm"),
     ("delta_experiment/scripts/run_film_tta.py", "film_adapter", ["--film-steps", "4", "--film-lr", "1e-2", "--num-groups", "2",
                                                                   "--film-mode", "shift_scale"], "correction_norm"),
+    ("delta_experiment/scripts/run_norm_tune_tta.py", "norm_tune", ["--norm-steps", "4", "--norm-lr", "1e-2", "--norm-target",
+                                                                    "all_norm"], "norm_param_drift"),
 ])
 def test_delta_runners_end_to_end(tmp_path, rel, method, extra, key):
     """delta wrapper -> anchored ES -> optimise -> hooks installed for the KV-cached continuation -> reference schemas."""
@@ -61,7 +63,7 @@ def test_delta_runners_end_to_end(tmp_path, rel, method, extra, key):
     s = json.loads((out / "summary.json").read_text())
     assert s["method"] == method and s["num_videos"] == 2 and s["num_successful"] == 2 and not (out / "config.json").exists()
     assert {"avg_train_time", "avg_es_check_time", "avg_gen_time", "avg_total_time"} <= set(s)
-    assert ("clip_gate_enabled" in s) == (method != "film_adapter")
+    assert ("clip_gate_enabled" in s) == (method not in ("film_adapter", "norm_tune"))
     for r in s["results"]:
         assert r["success"] and key in r and r["gen_time"] > 0 and r["final_loss"] is not None
         assert r["early_stopping_info"]["total_checks"] >= 1

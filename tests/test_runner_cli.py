@@ -100,6 +100,15 @@ def test_film_runner_parses_its_flags_and_has_no_clip_gate_group():
         m.build_parser().parse_args(common + ["--clip-gate-enabled"])
 
 
+def test_norm_tune_runner_parses_its_flags():
+    """run_norm_tune_tta.py:292-319 (no CLIP-gate group either)."""
+    m = _load_script("delta_experiment/scripts/run_norm_tune_tta.py")
+    i = _COMMON.index("--clip-gate-threshold")
+    common = _COMMON[:i] + _COMMON[i + 2:]
+    a = m.build_parser().parse_args(common + ["--norm-steps", "20", "--norm-lr", "1e-3", "--norm-target", "qk_norm"])
+    assert a.norm_target == "qk_norm" and a.norm_steps == 20 and a.also_tune_delta is False and not hasattr(a, "clip_gate_enabled")
+
+
 def test_baseline_runner_parses_the_reference_flags():
     """baseline_experiment/scripts/run_baseline.py:235-262."""
     m = _load_script("baseline_experiment/scripts/run_baseline.py")
