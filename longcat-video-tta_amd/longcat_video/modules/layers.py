@@ -176,6 +176,16 @@ class Attention(nn.Module):
         n_c = k_c.shape[1]
         T, Hh, Ww = shape
         t_c = n_c // (Hh * Ww)
+        sp = getattr(self, "_sp", None)
+        if sp is not None:  # frame-sharded noise tokens: global RoPE rows, all-gather of the fresh K/V, cond K/V replicated
+            cs = self.rope_3d.table((sp.num_frames + t_c, Hh, Ww), x.device)
+            q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+            ops.qknorm_rope(q, k, None, q, k, None, self.q_norm.weight, self.k_norm.weight, cs, n_c + sp.token_offset,
+                            self.q_norm.eps, q_scale=ops.log2_qscale(self.scale))
+            k_full, v_full = sp.all_gather_kv(k.contiguous(), v.contiguous())
+            ex = (lambda t: t if t.shape[0] == B else t.expand(B, -1, -1, -1))
+            o, _ = ops.attention(q, torch.cat([ex(k_c), k_full], dim=1), torch.cat([ex(v_c), v_full], dim=1), ops.LN2)
+            return _proj_out(self.proj, o.view(B, N, C), fuse_residual)
         cs = self.rope_3d.table((T + t_c, Hh, Ww), x.device)
         o = A.cached_attention(qkv, k_c, v_c, self.q_norm.weight, self.k_norm.weight, cs, self.scale,
                                self.q_norm.eps)

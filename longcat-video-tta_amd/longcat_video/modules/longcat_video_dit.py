@@ -139,10 +139,15 @@ class LongCatVideoTransformer3DModel(nn.Module):
         for b in self.blocks:
             b.attn._sp = None
 
-    def _forward_sp(self, hidden_states, timestep, encoder_hidden_states, encoder_attention_mask, num_cond_latents):
+    def _forward_sp(self, hidden_states, timestep, encoder_hidden_states, encoder_attention_mask, num_cond_latents,
+                    kv_cache_dict=None):
+        """Frame-sharded forward.  Without conditioning frames every rank takes its run of latent frames.  With the
+        conditioning-frame KV cache (`kv_cache_dict`: the cond K/V are small and REPLICATED - every rank computed them with
+        the plain path) the NOISE frames are sharded and each attention layer attends [cached cond | all-gathered noise]."""
         from ..parallel.sequence_parallel import SPContext
-        if num_cond_latents:
-            raise NotImplementedError("sequence parallelism with conditioning frames is not built yet")
+        if num_cond_latents and kv_cache_dict is None:
+            raise NotImplementedError("sequence parallelism with conditioning frames pinned in the sequence: use the KV cache "
+                                      "(pipeline use_kv_cache=True), which shards the noise frames and replicates the cond K/V")
         B, _, T, H, W = hidden_states.shape
         N_h, N_w = H // self.patch_size[1], W // self.patch_size[2]
         sp = SPContext(T // self.patch_size[0], N_h * N_w, self._sp_group[0])
@@ -153,7 +158,8 @@ class LongCatVideoTransformer3DModel(nn.Module):
         try:
             self._sp_group, saved = None, self._sp_group      # the local call below is the plain path on this shard
             local = self.forward(hidden_states[:, :, sp.t0:sp.t1].contiguous(), timestep[:, sp.t0:sp.t1].contiguous(),
-                                 encoder_hidden_states, encoder_attention_mask, 0)
+                                 encoder_hidden_states, encoder_attention_mask, num_cond_latents if kv_cache_dict is not None else 0,
+                                 kv_cache_dict=kv_cache_dict)
         finally:
             self._sp_group = saved
             for b in self.blocks:
@@ -163,11 +169,9 @@ class LongCatVideoTransformer3DModel(nn.Module):
     # ------------------------------------------------------------------ forward
     def forward(self, hidden_states, timestep, encoder_hidden_states, encoder_attention_mask=None,
                 num_cond_latents=0, return_kv=False, kv_cache_dict=None, skip_crs_attn=False, **kwargs):
-        if getattr(self, "_sp_group", None) is not None:
-            if return_kv or kv_cache_dict is not None:
-                raise NotImplementedError("KV cache under sequence parallelism is not built yet")
+        if getattr(self, "_sp_group", None) is not None and not return_kv:  # (the cond-frame cache itself is computed replicated)
             return self._forward_sp(hidden_states, timestep, encoder_hidden_states, encoder_attention_mask,
-                                    num_cond_latents)
+                                    num_cond_latents, kv_cache_dict)
         B, _, T, H, W = hidden_states.shape
         N_t, N_h, N_w = T // self.patch_size[0], H // self.patch_size[1], W // self.patch_size[2]
         if len(timestep.shape) == 1:

@@ -38,8 +38,19 @@ def _worker(rank, world, port, out_path):
             got = m(hs, ts, y, mask.cuda(), num_cond_latents=0)
             m.disable_sequence_parallel()
         err = (torch.linalg.vector_norm(got - ref) / torch.linalg.vector_norm(ref)).item()
+        # conditioning-frame KV cache under SP: 2 clean frames cached (replicated), the 3 noise frames sharded 2 + 1
+        with torch.no_grad():
+            cond, noise = hs[:, :, :2].contiguous(), hs[:, :, 2:].contiguous()
+            empty = torch.zeros(1, 1, 16, 64, dtype=BF16, device="cuda")
+            _, kv = m(cond, torch.zeros(1, 2, dtype=BF16, device="cuda"), empty, None, return_kv=True, skip_crs_attn=True)
+            ref2 = m(noise, ts[:, 2:].contiguous(), y, mask.cuda(), num_cond_latents=2, kv_cache_dict=kv)
+            m.enable_sequence_parallel(None)
+            _, kv_sp = m(cond, torch.zeros(1, 2, dtype=BF16, device="cuda"), empty, None, return_kv=True, skip_crs_attn=True)
+            got2 = m(noise, ts[:, 2:].contiguous(), y, mask.cuda(), num_cond_latents=2, kv_cache_dict=kv_sp)
+            m.disable_sequence_parallel()
+        err2 = (torch.linalg.vector_norm(got2 - ref2) / torch.linalg.vector_norm(ref2)).item()
         if rank == 0:
-            Path(out_path).write_text(f"{err}")
+            Path(out_path).write_text(f"{err} {err2}")
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -48,7 +59,7 @@ def _worker(rank, world, port, out_path):
 def test_sequence_parallel_forward_matches_single_gpu(tmp_path):
     out = tmp_path / "err.txt"
     mp.spawn(_worker, args=(2, 29700 + os.getpid() % 200, str(out)), nprocs=2, join=True)
-    err = float(out.read_text())
-    print("SP vs single rel-L2:", err)
+    err, err2 = (float(x) for x in out.read_text().split())
+    print("SP vs single rel-L2:", err, "; with the conditioning-frame KV cache:", err2)
     # identical kernels on identical rows; only the attention's K/V tile boundaries can differ -> fp32-order noise
-    assert err < 2e-3
+    assert err < 2e-3 and err2 < 2e-3
