@@ -136,3 +136,34 @@ def test_vae_decode_720p_prefix_property():
     part = vae.decode(z[:, :, :4].contiguous())[0]
     assert part.shape == (1, 3, 13, 720, 1280)
     assert rel_l2(part, full[:, :, :13]) < 1e-6
+
+
+def test_attention_backward_k3_tta_rows_vs_fp32():
+    """The two-pass attention backward at the K3-TTA size (7 latent frames x 3 600 = 25 200 tokens, 32 heads): dV and dK of
+    a subset of KEY rows and dQ of a subset of QUERY rows against the fp32 formulas  P = exp(S - lse), dV = P^T dO,
+    dS = P * (dO V^T - rowsum(dO * O)), dK = scale * dS^T Q, dQ = scale * dS K  evaluated with PyTorch on the GPU."""
+    ops = _ops()
+    N = 25200
+    g = torch.Generator(device=DEV).manual_seed(606)
+    qkv = torch.randn((1, N, 3, H, D), generator=g, device=DEV).to(BF16)
+    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    scale = D ** -0.5
+    o, lse = ops.attention(q, k, v, scale, need_lse=True)
+    do = torch.randn((1, N, H, D), generator=g, device=DEV).to(BF16)
+    dqkv = torch.zeros_like(qkv)
+    ops.attention_bwd(q, k, v, o, do, lse, dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2], scale)
+    assert torch.isfinite(dqkv).all()
+    ks = torch.randint(0, N, (40,), generator=g, device=DEV)
+    rs = torch.randint(0, N, (40,), generator=g, device=DEV)
+    for h in (0, 13, 31):
+        qf, kf, vf, of, dof = (t[0, :, h].float() for t in (q, k, v, o, do))
+        delta = (dof * of).sum(-1)                                  # [N]
+        # key subset: all queries x 40 keys
+        p_ = torch.exp(qf @ kf[ks].t() * scale - lse[0, h][:, None])  # [N, 40]
+        ds = p_ * (dof @ vf[ks].t() - delta[:, None])
+        assert rel_l2(dqkv[0, ks, 2, h], p_.t() @ dof) < 8e-3, ("dV", h)
+        assert rel_l2(dqkv[0, ks, 1, h], scale * ds.t() @ qf) < 8e-3, ("dK", h)
+        # query subset: 40 queries x all keys
+        p2 = torch.exp(qf[rs] @ kf.t() * scale - lse[0, h][rs][:, None])  # [40, N]
+        ds2 = p2 * (dof[rs] @ vf.t() - delta[rs][:, None])
+        assert rel_l2(dqkv[0, rs, 0, h], scale * ds2 @ kf) < 8e-3, ("dQ", h)
