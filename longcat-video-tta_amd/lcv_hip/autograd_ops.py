@@ -282,6 +282,84 @@ def self_attention(qkv, wq, wk, cs, scale, n_cond, eps, return_kv=False):
     return o, kv
 
 
+class _SPSelfAttentionFn(torch.autograd.Function):
+    """Frame-sharded self-attention with its adjoint: forward all-gathers the roped K and V and runs
+    local-Q x full-KV; backward runs the two-pass kernels on (local Q, full K/V), sums dK / dV over the ranks and keeps this
+    rank's rows (the adjoint of the all-gather), then the q/k-norm + RoPE backward on the local rows.  Conditioning tokens
+    (the first `n_cond_glob` keys; `n_cond_loc` of them are local queries, always a prefix) attend conditioning keys only."""
+
+    @staticmethod
+    def forward(ctx, qkv, wq, wk, cs, scale, eps, sp, n_cond_loc, n_cond_glob):
+        B, N, _, H, D = qkv.shape
+        qk = torch.empty((B, N, 2, H, D), dtype=BF16, device=qkv.device)
+        ops.qknorm_rope(qkv[:, :, 0], qkv[:, :, 1], None, qk[:, :, 0], qk[:, :, 1], None, wq, wk, cs, sp.token_offset, eps,
+                        q_scale=ops.log2_qscale(scale))
+        k_full, v_full = sp.all_gather_kv(qk[:, :, 1].contiguous(), qkv[:, :, 2].contiguous())
+        q = qk[:, :, 0]
+        o = torch.empty((B, N, H, D), dtype=BF16, device=qkv.device)
+        lses = []
+        if n_cond_loc > 0:
+            _, l1 = ops.attention(q[:, :n_cond_loc], k_full[:, :n_cond_glob], v_full[:, :n_cond_glob], ops.LN2,
+                                  out=o[:, :n_cond_loc], need_lse=True)
+            lses.append(l1)
+        if N > n_cond_loc:
+            _, l2 = ops.attention(q[:, n_cond_loc:], k_full, v_full, ops.LN2, out=o[:, n_cond_loc:], need_lse=True)
+            lses.append(l2)
+        ctx.save_for_backward(qkv, qk, k_full, v_full, o, wq, wk, cs, *lses)
+        ctx.args = (scale, eps, sp, n_cond_loc, n_cond_glob)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, qk, k_full, v_full, o, wq, wk, cs, *lses = ctx.saved_tensors
+        scale, eps, sp, n_cond_loc, n_cond_glob = ctx.args
+        B, N, _, H, D = qkv.shape
+        do = do.contiguous()
+        q = qk[:, :, 0]
+        dq = torch.zeros((B, N, H, D), dtype=BF16, device=qkv.device)
+        dk_full = torch.zeros_like(k_full)
+        dv_full = torch.zeros_like(v_full)
+        i = 0
+        if n_cond_loc > 0:
+            ops.attention_bwd(q[:, :n_cond_loc], k_full[:, :n_cond_glob], v_full[:, :n_cond_glob], o[:, :n_cond_loc],
+                              do[:, :n_cond_loc], lses[i], dq[:, :n_cond_loc], dk_full[:, :n_cond_glob],
+                              dv_full[:, :n_cond_glob], ops.LN2, accumulate_kv=False)
+            i += 1
+        if N > n_cond_loc:
+            ops.attention_bwd(q[:, n_cond_loc:], k_full, v_full, o[:, n_cond_loc:], do[:, n_cond_loc:], lses[i],
+                              dq[:, n_cond_loc:], dk_full, dv_full, ops.LN2, accumulate_kv=(n_cond_loc > 0))
+        dk = sp.reduce_scatter_kv(dk_full)
+        dv = sp.reduce_scatter_kv(dv_full)
+        dqkv = torch.empty_like(qkv)
+        want_dw = wq.requires_grad or wk.requires_grad
+        dwq = torch.zeros(D, dtype=torch.float32, device=qkv.device) if want_dw else None
+        dwk = torch.zeros(D, dtype=torch.float32, device=qkv.device) if want_dw else None
+        ops.qknorm_rope_bwd(qkv[:, :, 0], qkv[:, :, 1], dq, dk, dqkv[:, :, 0], dqkv[:, :, 1], wq, wk, cs, sp.token_offset, eps,
+                            q_scale=ops.log2_qscale(scale), dwq=dwq, dwk=dwk)
+        dqkv[:, :, 2].copy_(dv)
+        return (dqkv, dwq.to(wq.dtype) if (want_dw and wq.requires_grad) else None,
+                dwk.to(wk.dtype) if (want_dw and wk.requires_grad) else None, None, None, None, None, None, None)
+
+
+def sp_self_attention(qkv, wq, wk, cs, scale, eps, sp, n_cond_loc, n_cond_glob):
+    """Sequence-parallel self-attention on a fresh local qkv [B, n_local, 3, H, D]; autograd-aware."""
+    if _needs_grad(qkv, wq, wk):
+        return _SPSelfAttentionFn.apply(qkv, wq, wk, cs, scale, eps, sp, n_cond_loc, n_cond_glob)
+    B, N, _, H, D = qkv.shape
+    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    ops.qknorm_rope(q, k, None, q, k, None, wq, wk, cs, sp.token_offset, eps, q_scale=ops.log2_qscale(scale))
+    k_full, v_full = sp.all_gather_kv(k.contiguous(), v.contiguous())
+    if n_cond_glob == 0:
+        o, _ = ops.attention(q, k_full, v_full, ops.LN2)
+        return o
+    o = torch.empty((B, N, H, D), dtype=BF16, device=qkv.device)
+    if n_cond_loc > 0:
+        ops.attention(q[:, :n_cond_loc], k_full[:, :n_cond_glob], v_full[:, :n_cond_glob], ops.LN2, out=o[:, :n_cond_loc])
+    if N > n_cond_loc:
+        ops.attention(q[:, n_cond_loc:], k_full, v_full, ops.LN2, out=o[:, n_cond_loc:])
+    return o
+
+
 def cached_attention(qkv, k_c, v_c, wq, wk, cs, scale, eps):
     """Noise-token queries against [cached cond K/V | fresh K/V]; inference only."""
     if _needs_grad(qkv):

@@ -153,18 +153,15 @@ class Attention(nn.Module):
         return out
 
     def _forward_sequence_parallel(self, qkv, shape, num_cond_latents, sp, fuse_residual=None):
-        """Frame-sharded tokens: RoPE at GLOBAL positions, all-gather of K/V (post-norm, post-RoPE), local-Q x full-KV."""
-        if torch.is_grad_enabled() and qkv.requires_grad:
-            raise NotImplementedError("sequence-parallel attention is an inference path this round (dK/dV reduce-scatter next)")
-        if num_cond_latents:
-            raise NotImplementedError("sequence parallelism with conditioning frames: shard the noise frames, replicate cond K/V (next)")
+        """Frame-sharded tokens: RoPE at GLOBAL positions, all-gather of K/V (post-norm, post-RoPE), local-Q x full-KV;
+        `num_cond_latents` is this rank's LOCAL count of conditioning frames (a prefix of its shard), the global count comes
+        from the SP context.  Differentiable (dK / dV are summed over the ranks in the backward)."""
         B, N, _, H, D = qkv.shape
+        S = shape[1] * shape[2]
         cs = self.rope_3d.table((sp.num_frames, shape[1], shape[2]), qkv.device)
-        q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
-        ops.qknorm_rope(q, k, None, q, k, None, self.q_norm.weight, self.k_norm.weight, cs, sp.token_offset, self.q_norm.eps,
-                        q_scale=ops.log2_qscale(self.scale))
-        k_full, v_full = sp.all_gather_kv(k.contiguous(), v.contiguous())
-        o, _ = ops.attention(q, k_full, v_full, ops.LN2)
+        n_loc = int(num_cond_latents or 0) * S
+        n_glob = int(getattr(sp, "num_cond_frames", 0)) * S
+        o = A.sp_self_attention(qkv, self.q_norm.weight, self.k_norm.weight, cs, self.scale, self.q_norm.eps, sp, n_loc, n_glob)
         return _proj_out(self.proj, o.view(B, N, H * D), fuse_residual)
 
     def forward_with_kv_cache(self, x, shape=None, num_cond_latents=None, kv_cache=None, fuse_residual=None):

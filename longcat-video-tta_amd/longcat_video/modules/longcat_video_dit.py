@@ -139,15 +139,20 @@ class LongCatVideoTransformer3DModel(nn.Module):
         for b in self.blocks:
             b.attn._sp = None
 
+    def sequence_parallel_sync_grads(self, params) -> None:
+        """Under sequence parallelism every rank back-propagates through its own frame shard only, so parameter gradients
+        (LoRA adapters, deltas, ...) are partial sums: all-reduce them before the optimizer step."""
+        if self._sp_group is None:
+            return
+        from ..parallel.sequence_parallel import SPContext
+        SPContext(1, 1, self._sp_group[0]).all_reduce_grads(params)
+
     def _forward_sp(self, hidden_states, timestep, encoder_hidden_states, encoder_attention_mask, num_cond_latents,
                     kv_cache_dict=None):
         """Frame-sharded forward.  Without conditioning frames every rank takes its run of latent frames.  With the
         conditioning-frame KV cache (`kv_cache_dict`: the cond K/V are small and REPLICATED - every rank computed them with
         the plain path) the NOISE frames are sharded and each attention layer attends [cached cond | all-gathered noise]."""
         from ..parallel.sequence_parallel import SPContext
-        if num_cond_latents and kv_cache_dict is None:
-            raise NotImplementedError("sequence parallelism with conditioning frames pinned in the sequence: use the KV cache "
-                                      "(pipeline use_kv_cache=True), which shards the noise frames and replicates the cond K/V")
         B, _, T, H, W = hidden_states.shape
         N_h, N_w = H // self.patch_size[1], W // self.patch_size[2]
         sp = SPContext(T // self.patch_size[0], N_h * N_w, self._sp_group[0])
@@ -157,13 +162,19 @@ class LongCatVideoTransformer3DModel(nn.Module):
             b.attn._sp = sp
         try:
             self._sp_group, saved = None, self._sp_group      # the local call below is the plain path on this shard
+            if kv_cache_dict is not None:
+                ncl_local = num_cond_latents          # cond K/V come from the (replicated) cache; only noise frames are here
+            else:                                     # cond frames pinned in the sequence: the lowest frames, maybe split over ranks
+                sp.num_cond_frames = int(num_cond_latents or 0)
+                ncl_local = max(0, min(sp.t1, sp.num_cond_frames) - sp.t0)
             local = self.forward(hidden_states[:, :, sp.t0:sp.t1].contiguous(), timestep[:, sp.t0:sp.t1].contiguous(),
-                                 encoder_hidden_states, encoder_attention_mask, num_cond_latents if kv_cache_dict is not None else 0,
-                                 kv_cache_dict=kv_cache_dict)
+                                 encoder_hidden_states, encoder_attention_mask, ncl_local, kv_cache_dict=kv_cache_dict)
         finally:
             self._sp_group = saved
             for b in self.blocks:
                 b.attn._sp = None
+        if torch.is_grad_enabled() and local.requires_grad:
+            return sp.gather_frames_autograd(local)
         return sp.gather_frames(local)
 
     # ------------------------------------------------------------------ forward

@@ -86,9 +86,39 @@ class SPContext:
         v = self._coll(lambda t: _gather_rows(t, self.counts, self.S, self.group), v_local)
         return k, v
 
+    def reduce_scatter_kv(self, d_full: torch.Tensor) -> torch.Tensor:
+        """Adjoint of `all_gather_kv` for one tensor: sum the full-length gradient over ranks, keep this rank's rows."""
+        return self._coll(lambda t: reduce_scatter_kv_grad(t, self.counts, self.S, self.group), d_full)
+
+    def gather_frames_autograd(self, x_local: torch.Tensor) -> torch.Tensor:
+        """`gather_frames` with a backward: every rank evaluates the SAME loss on the gathered prediction, so the gradient
+        w.r.t. the full tensor is identical everywhere and each rank simply keeps the slice of its own frames."""
+        return _GatherFramesFn.apply(x_local, self)
+
+    def all_reduce_grads(self, params) -> None:
+        """Each rank back-propagates through its own token shard only: parameter gradients are partial sums."""
+        import torch.distributed as dist
+        for p_ in params:
+            if p_.grad is not None:
+                g = p_.grad
+                r = self._coll(lambda t: (dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group), t)[1], g.contiguous())
+                p_.grad = r.to(g.dtype)
+
     def gather_frames(self, x_local: torch.Tensor) -> torch.Tensor:
         """[B, C, T_local, H, W] -> [B, C, T, H, W] on every rank."""
         B, C, Tl, H, W = x_local.shape
         rows = x_local.permute(0, 2, 1, 3, 4).reshape(B, Tl, C * H * W).contiguous()
         full = self._coll(lambda t: _gather_rows(t, self.counts, 1, self.group), rows)
         return full.view(B, self.num_frames, C, H, W).permute(0, 2, 1, 3, 4).contiguous()
+
+
+class _GatherFramesFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_local, sp):
+        ctx.sp = sp
+        return sp.gather_frames(x_local)
+
+    @staticmethod
+    def backward(ctx, dfull):
+        sp = ctx.sp
+        return dfull[:, :, sp.t0:sp.t1].contiguous(), None

@@ -87,6 +87,8 @@ def finetune_lora_on_conditioning(dit: nn.Module, lora_modules, cond_latents: to
                                                       prompt_embeds=prompt_embeds, prompt_mask=prompt_mask,
                                                       device=device, dtype=dtype)
         loss.backward()
+        if getattr(dit, "_sp_group", None) is not None:   # frame-sharded forward: the adapter gradients are partial sums
+            dit.sequence_parallel_sync_grads(optimizer.params)
         optimizer.clip_grad_norm_(max_grad_norm)
         optimizer.step()
         losses.append(loss.item())

@@ -63,3 +63,72 @@ def test_sequence_parallel_forward_matches_single_gpu(tmp_path):
     print("SP vs single rel-L2:", err, "; with the conditioning-frame KV cache:", err2)
     # identical kernels on identical rows; only the attention's K/V tile boundaries can differ -> fp32-order noise
     assert err < 2e-3 and err2 < 2e-3
+
+
+def _train_worker(rank, world, port, out_path):
+    for p in (str(ROOT), str(ROOT / "longcat-video-tta_amd")):
+        sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import dit_oracle as orc
+        from longcat_video.modules.longcat_video_dit import LongCatVideoTransformer3DModel
+        from tta.flow_matching import fm_mse_loss
+        from tta.lora import get_lora_parameters, inject_lora_into_dit
+        BF16 = torch.bfloat16
+        cfg = orc.small_config(hidden_size=256, depth=2, num_heads=2, caption_channels=64)
+        P = orc.make_params(cfg, seed=9, std=0.05)
+        m = LongCatVideoTransformer3DModel(device="cuda", dtype=BF16, hidden_size=256, depth=2, num_heads=2,
+                                           caption_channels=64, adaln_tembed_dim=64)
+        m.load_state_dict(P, strict=False)
+        for p_ in m.parameters():
+            p_.requires_grad = False
+        torch.manual_seed(3)                       # identical adapters on every rank
+        mods = inject_lora_into_dit(m, rank=4, alpha=8.0, target_modules=["qkv", "proj"])
+        params = get_lora_parameters(mods)
+        g = torch.Generator().manual_seed(7)
+        with torch.no_grad():                      # B is zero-initialised: give it a value so every gradient is non-trivial
+            for p_ in params:
+                p_.copy_((torch.randn(p_.shape, generator=g) * 0.05).to(BF16))
+        m.train()
+        ncond = 2                                  # 2 clean + 3 noised frames; shards 3 + 2 -> rank 0 holds cond AND noise frames
+        hs = torch.randn(1, 16, 5, 8, 12, generator=g).to(BF16).cuda()
+        y = torch.randn(1, 1, 16, 64, generator=g).to(BF16).cuda()
+        mask = torch.zeros(1, 16, dtype=torch.int64); mask[:, :10] = 1; mask = mask.cuda()
+        ts = torch.tensor([[0.0, 0.0, 500.0, 500.0, 500.0]]).to(BF16).cuda()
+        eps = torch.randn(1, 16, 3, 8, 12, generator=g).to(BF16).cuda(); x0 = torch.randn(1, 16, 3, 8, 12, generator=g).to(BF16).cuda()
+
+        def run():
+            for p_ in params:
+                p_.grad = None
+            pred = m(hs, ts, y, mask, num_cond_latents=ncond)
+            loss = fm_mse_loss(pred, eps, x0, ncond)
+            loss.backward()
+            return loss.item(), pred.detach()
+        l_ref, pred_ref = run()
+        g_ref = [p_.grad.detach().float().clone() for p_ in params]
+        m.enable_sequence_parallel(None)
+        l_sp, pred_sp = run()
+        m.sequence_parallel_sync_grads(params)
+        m.disable_sequence_parallel()
+        g_sp = [p_.grad.detach().float() for p_ in params]
+        num = sum(((a - b) ** 2).sum() for a, b in zip(g_sp, g_ref)).sqrt().item()
+        den = sum((b ** 2).sum() for b in g_ref).sqrt().item()
+        worst = max(((a - b).norm() / (b.norm() + 1e-12)).item() for a, b in zip(g_sp, g_ref))
+        perr = (torch.linalg.vector_norm(pred_sp - pred_ref) / torch.linalg.vector_norm(pred_ref)).item()
+        if rank == 0:
+            Path(out_path).write_text(f"{abs(l_sp - l_ref) / abs(l_ref)} {perr} {num / den} {worst}")
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sequence_parallel_training_gradients_match_single_gpu(tmp_path):
+    """TTA under SP: conditioning frames pinned in the sequence (split 3 + 2 over the ranks, so one rank holds conditioning
+    AND noise queries), differentiable frame gather, dK / dV summed over ranks inside the attention backward, adapter
+    gradients all-reduced: loss, prediction and LoRA gradients equal the single-process ones."""
+    out = tmp_path / "g.txt"
+    mp.spawn(_train_worker, args=(2, 29950 + os.getpid() % 40, str(out)), nprocs=2, join=True)
+    dl, perr, gerr, worst = (float(x) for x in out.read_text().split())
+    print("SP training: loss rel diff", dl, "pred rel-L2", perr, "LoRA grad rel-L2 (all / worst tensor)", gerr, worst)
+    assert dl < 2e-3 and perr < 2e-3 and gerr < 2e-2 and worst < 6e-2
