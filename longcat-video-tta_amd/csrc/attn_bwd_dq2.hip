@@ -1,0 +1,240 @@
+// Attention backward, pass B (dQ), second form - for the self-attention path where q is pre-scaled into log2 units
+// (scale * log2(e) == 1; attn_fwd.hip, VAR bit 1).  Same geometry as attn_bwd_dq_kernel (8 waves x 32 query rows, 64-key tiles,
+// query on the lane, S^T = K Q^T, dP^T = V dO^T, dQ^T += K^T dS^T), rebuilt like the forward kernel:
+//   * K / V tiles by LDS-DMA from per-lane pointers that advance one tile per iteration (no staging registers, no ds_write);
+//   * tile loop unrolled by two with compile-time buffers, the last (possibly ragged) tile peeled, so the steady-state body has
+//     neither mask code nor ragged-row code;
+//   * row constants as the initial accumulator (cdna_hip_programming.md, attention backward): the score accumulators START at
+//     -lse (log2 units), so P = exp2(accumulator) needs no multiply-subtract, and the softmax scale is applied once to dQ in the
+//     epilogue instead of to every dS:  dS' = P * (dP - delta)  is 2 vector instructions per score instead of 5.
+// This loop, like the forward, is vector-issue bound: the file is built without SLP vectorisation (lcv_hip/build.py).
+#include "lcv_common.h"
+#include <type_traits>
+
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+typedef __attribute__((address_space(1))) void gbl_void_q;
+typedef __attribute__((address_space(3))) void lds_void_q;
+#define AS3 __attribute__((address_space(3)))
+
+struct AttnBwdDq2Params {
+  const bf16_t* q;
+  const bf16_t* k;
+  const bf16_t* v;
+  const bf16_t* d_o;
+  const float* lse;
+  const float* delta;
+  bf16_t* dq;
+  int64_t Nq, Nk;
+  int H;
+  int64_t q_sb, q_sn, q_sh, k_sb, k_sn, k_sh, v_sb, v_sn, v_sh, o_sb, o_sn, o_sh, dq_sb, dq_sn, dq_sh;
+  float scale;
+};
+
+__global__ __launch_bounds__(512) void attn_bwd_dq2_kernel(const AttnBwdDq2Params p) {
+  constexpr int QROWS = 256;
+  constexpr int TILE_BYTES = 64 * 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  lds_u8* lds = (lds_u8*)smem;  // [2][K tile | V tile]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int head = blockIdx.y;
+  const int64_t b = blockIdx.z;
+  const int64_t q0 = (int64_t)blockIdx.x * QROWS + wave * 32;
+  const bf16_t* kbase = p.k + b * p.k_sb + (int64_t)head * p.k_sh;
+  const bf16_t* vbase = p.v + b * p.v_sb + (int64_t)head * p.v_sh;
+
+  bf16x8 qf[8], dof[8];
+  f32x16 sinit;  // -lse (log2 units) of this lane's query in every element: the C operand of each tile's first score MFMA
+  float delta_q;
+  {
+    int64_t qrow = q0 + r;
+    if (qrow > p.Nq - 1) qrow = p.Nq - 1;
+    const bf16_t* qp = p.q + b * p.q_sb + qrow * p.q_sn + (int64_t)head * p.q_sh + 8 * h;
+    const bf16_t* dp_ = p.d_o + b * p.o_sb + qrow * p.o_sn + (int64_t)head * p.o_sh + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      qf[ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
+      dof[ks] = *reinterpret_cast<const bf16x8*>(dp_ + 16 * ks);
+    }
+    const float nl = -p.lse[(b * p.H + head) * p.Nq + qrow] * 1.4426950408889634f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sinit[e] = nl;
+    delta_q = p.delta[(b * p.H + head) * p.Nq + qrow];
+  }
+
+  // LDS-DMA roles (as attn_fwd.hip): wave w fills rows 8 w .. 8 w + 7 of both tiles, 2 + 2 one-KiB instructions
+  const bf16_t* kdma[2];
+  const bf16_t* vdma[2];
+  int dma_row[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    dma_row[i] = 8 * wave + 4 * i + (lane >> 4);
+    const int col = 8 * ((lane & 15) ^ (((dma_row[i] & 3) << 2) | ((dma_row[i] >> 2) & 3)));
+    kdma[i] = kbase + dma_row[i] * p.k_sn + col;
+    vdma[i] = vbase + dma_row[i] * p.v_sn + col;
+  }
+  auto dma_tile = [&](int t, int buf, auto full_c) {
+    constexpr bool FULL = decltype(full_c)::value;
+    lds_u8* dst = lds + buf * 2 * TILE_BYTES + wave * 2048;
+    if (FULL || (int64_t)t * 64 + 64 <= p.Nk) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        __builtin_amdgcn_global_load_lds((gbl_void_q*)kdma[i], (lds_void_q*)(dst + 1024 * i), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void_q*)vdma[i], (lds_void_q*)(dst + TILE_BYTES + 1024 * i), 16, 0, 0);
+        kdma[i] += 64 * p.k_sn;
+        vdma[i] += 64 * p.v_sn;
+      }
+    } else {  // ragged last tile: rows past Nk re-read the last key (masked below)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        int64_t back = (int64_t)t * 64 + dma_row[i] - (p.Nk - 1);
+        if (back < 0) back = 0;
+        __builtin_amdgcn_global_load_lds((gbl_void_q*)(kdma[i] - back * p.k_sn), (lds_void_q*)(dst + 1024 * i), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void_q*)(vdma[i] - back * p.v_sn), (lds_void_q*)(dst + TILE_BYTES + 1024 * i), 16, 0, 0);
+      }
+    }
+  };
+
+  const int kfz = ((r & 3) << 2) | ((r >> 2) & 3);
+  const int k_row_off = 256 * r;
+  const int q4 = (lane >> 2) & 3, p4 = lane & 3, g1 = (lane >> 4) & 1;
+  int t_base[2], t_low[2];
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    t_base[half] = 256 * (4 * h + 8 * half + q4) + 8 * (p4 & 1);
+    t_low[half] = (2 * g1 + (p4 >> 1)) ^ (h + 2 * half);
+  }
+
+  f32x16 dqacc[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dqacc[d][e] = 0.f;
+
+  const int nt = (int)((p.Nk + 63) / 64);
+  dma_tile(0, 0, std::false_type{});
+  __syncthreads();  // (drains this wave's LDS-DMA: vmcnt 0)
+
+  auto tile_body = [&](const int t, auto buf_c, auto last_c, auto next_full_c) {
+    constexpr int buf = decltype(buf_c)::value;
+    constexpr bool has_next = !decltype(last_c)::value;
+    if (has_next) dma_tile(t + 1, buf ^ 1, next_full_c);
+    const lds_u8* kb = lds + buf * 2 * TILE_BYTES;
+    const lds_u8* vb = kb + TILE_BYTES;
+
+    f32x16 s0, s1, d0, d1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { s0[e] = sinit[e]; s1[e] = sinit[e]; d0[e] = 0.f; d1[e] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const int co = 16 * ((2 * ks + h) ^ kfz);
+      const bf16x8 a0 = *reinterpret_cast<const AS3 bf16x8*>(kb + k_row_off + co);
+      const bf16x8 a1 = *reinterpret_cast<const AS3 bf16x8*>(kb + 32 * 256 + k_row_off + co);
+      s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qf[ks], s0, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qf[ks], s1, 0, 0, 0);
+      const bf16x8 c0 = *reinterpret_cast<const AS3 bf16x8*>(vb + k_row_off + co);
+      const bf16x8 c1 = *reinterpret_cast<const AS3 bf16x8*>(vb + 32 * 256 + k_row_off + co);
+      d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c0, dof[ks], d0, 0, 0, 0);
+      d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c1, dof[ks], d1, 0, 0, 0);
+    }
+    if (!has_next && (p.Nk & 63)) {  // last tile only
+      const int valid = (int)(p.Nk - (int64_t)t * 64);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int key = (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (key >= valid) s0[e] = -INFINITY;
+        if (key + 32 >= valid) s1[e] = -INFINITY;
+      }
+    }
+    // dS' = P * (dP - delta), P = exp2(S - lse): the scale is applied to dQ once, in the epilogue
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      s0[e] = __builtin_amdgcn_exp2f(s0[e]) * (d0[e] - delta_q);
+      s1[e] = __builtin_amdgcn_exp2f(s1[e]) * (d1[e] - delta_q);
+    }
+    bf16x8 dsb[4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      dsb[0][j] = (__bf16)s0[j];
+      dsb[1][j] = (__bf16)s0[8 + j];
+      dsb[2][j] = (__bf16)s1[j];
+      dsb[3][j] = (__bf16)s1[8 + j];
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const int dx = 64 * (d ^ q4);
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((AS3 s16x4*)(kb + t_base[0] + 4096 * kk + dx + 16 * t_low[0]));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((AS3 s16x4*)(kb + t_base[1] + 4096 * kk + dx + 16 * t_low[1]));
+        const bf16x8 ktf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        dqacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, dsb[kk], dqacc[d], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  };
+  {
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    using Y = std::true_type;
+    using N = std::false_type;
+    int t = 0;
+    for (; t + 3 < nt; t += 2) {
+      tile_body(t, B0{}, N{}, Y{});
+      tile_body(t + 1, B1{}, N{}, Y{});
+    }
+    const int left = nt - t;
+    if (left == 3) {
+      tile_body(t, B0{}, N{}, Y{});
+      tile_body(t + 1, B1{}, N{}, N{});
+      tile_body(t + 2, B0{}, Y{}, N{});
+    } else if (left == 2) {
+      tile_body(t, B0{}, N{}, N{});
+      tile_body(t + 1, B1{}, Y{}, N{});
+    } else {
+      tile_body(t, B0{}, Y{}, N{});
+    }
+  }
+
+  const int64_t qrow = q0 + r;
+  if (qrow < p.Nq) {
+    bf16_t* dqp = p.dq + b * p.dq_sb + qrow * p.dq_sn + (int64_t)head * p.dq_sh;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        u16x4 pk;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pk[e] = f2bf(dqacc[d][4 * i + e] * p.scale);
+        *reinterpret_cast<u16x4*>(dqp + 32 * d + 8 * i + 4 * h) = pk;
+      }
+  }
+}
+
+// called by lcv_attn_bwd (attn_bwd.hip) when scale * log2(e) == 1 and LCV_ATTN_BWD_VAR != 0
+int attn_bwd_dq2_launch(const void* q, const void* k, const void* v, const void* d_o, const float* lse, const float* delta,
+                        void* dq, int64_t B, int64_t H, int64_t Nq, int64_t Nk, int64_t q_sb, int64_t q_sn, int64_t q_sh,
+                        int64_t k_sb, int64_t k_sn, int64_t k_sh, int64_t v_sb, int64_t v_sn, int64_t v_sh, int64_t o_sb,
+                        int64_t o_sn, int64_t o_sh, int64_t dq_sb, int64_t dq_sn, int64_t dq_sh, float scale, hipStream_t s) {
+  AttnBwdDq2Params p;
+  p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.d_o = (const bf16_t*)d_o;
+  p.lse = lse; p.delta = delta; p.dq = (bf16_t*)dq; p.Nq = Nq; p.Nk = Nk; p.H = (int)H;
+  p.q_sb = q_sb; p.q_sn = q_sn; p.q_sh = q_sh; p.k_sb = k_sb; p.k_sn = k_sn; p.k_sh = k_sh;
+  p.v_sb = v_sb; p.v_sn = v_sn; p.v_sh = v_sh; p.o_sb = o_sb; p.o_sn = o_sn; p.o_sh = o_sh;
+  p.dq_sb = dq_sb; p.dq_sn = dq_sn; p.dq_sh = dq_sh; p.scale = scale;
+  const size_t lds = 2 * 2 * 64 * 256;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)attn_bwd_dq2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      lcv_set_error("attn_bwd: cannot raise dynamic LDS");
+      return LCV_EDEVICE;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(attn_bwd_dq2_kernel, dim3((unsigned)((Nq + 255) / 256), (unsigned)H, (unsigned)B), dim3(512), lds, s, p);
+  LCV_LAUNCH_CHECK("attn_bwd_dq2");
+  return LCV_OK;
+}

@@ -34,6 +34,22 @@ if which in ("attn_unit",):
         ms=timeit(lambda: ops.attention(q_pre,qkv[:,:,1],qkv[:,:,2],math.log(2.0),out=o2), n=3, warm=1)
         print(f"attn unit    N={N}: {ms:.2f} ms  {fl/ms/1e9:.1f} TF/s", flush=True)
         d=(o.float()-o2.float()); print("rel_l2 unit vs general:", (d.norm()/o.float().norm()).item(), "max abs", d.abs().max().item())
+if which in ("attn_bwd",):
+    import math
+    N=25200; H=32; D=128
+    qkv=torch.randn(1,N,3,H,D,device=dev,dtype=torch.float32)
+    c=D**-0.5*math.log2(math.e)
+    q=(qkv[:,:,0]*c).to(bf).contiguous(); k=qkv[:,:,1].to(bf).contiguous(); v=qkv[:,:,2].to(bf).contiguous()
+    o,lse=ops.attention(q,k,v,math.log(2.0),need_lse=True)
+    do=torch.randn(1,N,H,D,device=dev,dtype=bf)
+    dq=torch.empty_like(q); dk=torch.empty_like(k); dv=torch.empty_like(v)
+    outs={}
+    for var in ("0","1","2","3","0","3"):
+        os.environ["LCV_ATTN_BWD_VAR"]=var
+        ms=timeit(lambda: ops.attention_bwd(q,k,v,o,do,lse,dq,dk,dv,math.log(2.0)), n=3, warm=1)
+        outs[var]=dq.clone()
+        print(f"attn_bwd var={var} N={N}: {ms:.2f} ms  (fwd-equivalent {10*N*N*H*D/ms/1e9:.1f} TF/s algorithmic)", flush=True)
+    d=(outs["0"].float()-outs["3"].float()); print("dq rel_l2 new vs old:", (d.norm()/outs["0"].float().norm()).item())
 if which in ("gemm_group",):
     for (M,N,K,name) in ((46800,12288,4096,"qkv"),(46800,4096,4096,"proj"),(46800,22016,4096,"w13"),(46800,4096,11008,"w2")):
         a=torch.randn(M,K,device=dev,dtype=bf); w=torch.randn(N,K,device=dev,dtype=bf)*0.02; b=torch.randn(N,device=dev,dtype=bf)
