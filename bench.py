@@ -88,11 +88,29 @@ def cpu_baseline(num_inference_steps: int) -> dict:
     per_block = min(times[1:] or times) / 2
     fwd48 = per_block * 48
     sec_per_step = 2 * fwd48  # CFG: two forwards per step
+    # One LoRA-TTA inner step on the same sample: forward + LoRA-only backward through the same 2 blocks
+    # with rank-8 adapters on qkv/proj folded in as W + s*B*A (torch autograd over the oracle), extrapolated to 48 blocks.
+    leaves = []
+    P2 = dict(P)
+    for i in range(2):
+        for n_ in ("attn.qkv", "attn.proj"):
+            W_ = P[f"blocks.{i}.{n_}.weight"]
+            A_ = (torch.randn(8, W_.shape[1], generator=g) * 0.02).requires_grad_(True)
+            B_ = torch.zeros(W_.shape[0], 8, requires_grad=True)
+            P2[f"blocks.{i}.{n_}.weight"] = W_ + 2.0 * (B_ @ A_)
+            leaves += [A_, B_]
+    t0 = time.perf_counter()
+    out = xe
+    for i in range(2):
+        out = orc.block_forward(P2, f"blocks.{i}.", out, ye, t, lens, (N_t, N_h, N_w), 0, 32)
+    out.square().mean().backward()
+    tta_step48 = (time.perf_counter() - t0) / 2 * 48
     return {"value": T / (num_inference_steps * sec_per_step), "unit": "denoised latent frames/s", "cores": cores,
-            "kind": "port",
+            "kind": "port", "tta_inner_step_s": round(tta_step48, 1),
             "sample": f"K1 {WORKLOADS['K1'][3]}: 2 of 48 blocks at full width timed (best of {max(len(times) - 1, 1)} after warm-up, "
                       f"{per_block:.2f} s/block), linear extrapolation to 48 blocks x 2 CFG forwards; fp32 math at "
-                      "the bf16 rounding points"}
+                      "the bf16 rounding points; tta_inner_step_s = one forward + LoRA-only backward (rank 8 on qkv+proj) "
+                      "of the same 2 blocks, x24"}
 
 
 def measure_reference_point(dit, dev, pe, pm, ne, nm) -> dict:
