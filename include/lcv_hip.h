@@ -275,6 +275,22 @@ int lcv_vae_rmsnorm_silu(const void* x, const void* gamma, void* y, int64_t rows
 int lcv_softmax_rows(const float* s, void* p, int64_t rows, int64_t n, int64_t ld_s, int64_t ld_p, float scale,
                      void* stream);
 
+/* ---- on-device evaluation of generated frames -------------------------------------------------
+ * Replaces the host loops of evaluate_generation_metrics (delta_experiment/scripts/common.py:663-757) and of the
+ * baseline runner (baseline_experiment/scripts/run_baseline.py:124-145, 436-441): per-frame sum((gen-gt)^2) for PSNR
+ * and a separable-window SSIM map summed over the windows that lie inside the frame — which is what survives
+ * torchmetrics' pad-5/crop-5 (`StructuralSimilarityIndexMeasure(data_range=1.0)`: win 11, Gaussian sigma 1.5,
+ * cov_norm 1, clamp_var 1; common.py:760-764) and skimage's crop of (win-1)/2 (`structural_similarity` defaults:
+ * win 7, uniform taps 1/7, cov_norm 49/48, clamp_var 0; run_baseline.py:135-136).
+ * Frames are NHWC [N,H,W,C], C interleaved (C <= 4); `gen` fp32 in [0,1]; `gt` fp32 or raw uint8 (gt_is_u8: divided
+ * by 255 in the kernel).  Each call writes fp32 partial sums, [N, n_sqerr] / [N, n_ssim] as sized by
+ * lcv_frame_metric_partials; the caller adds them (fp64) and divides by H*W*C, resp. (H-win+1)*(W-win+1)*C. */
+int lcv_frame_metric_partials(int64_t H, int64_t W, int64_t C, int win, int64_t* n_sqerr, int64_t* n_ssim);
+int lcv_frame_sqerr(const float* gen, const void* gt, int gt_is_u8, float* partials, int64_t N, int64_t E, void* stream);
+int lcv_frame_ssim(const float* gen, const void* gt, int gt_is_u8, float* partials, int64_t N, int64_t H, int64_t W,
+                   int64_t C, const float* window /* host pointer, `win` normalised taps */, int win, float cov_norm,
+                   int clamp_var, float c1, float c2, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -42,6 +42,14 @@ def build_parser():
     return p
 
 
+def _stats(vals):
+    """run_baseline.py:547-554: mean / std / min / max to 4 places, {} when nothing was scored."""
+    if not vals:
+        return {}
+    return {"mean": round(float(np.mean(vals)), 4), "std": round(float(np.std(vals)), 4), "min": round(min(vals), 4),
+            "max": round(max(vals), 4)}
+
+
 def main(argv=None):
     args = build_parser().parse_args(argv)
     wall_start = time.time()
@@ -63,9 +71,19 @@ def main(argv=None):
             out, dt = R.generate_continuation(pipe, blob, args, idx, device, num_frames=num_frames)
             row = {"idx": idx, "index": idx, "filename": e["name"], "caption": blob.get("caption", ""), "psnr": None,
                    "ssim": None, "lpips": None, "resolution": args.resolution, "inference_time_s": round(dt, 2)}
-            if args.save_videos and pipe.vae is not None:
-                (out_dir / "videos").mkdir(exist_ok=True)
-                R.save_frames(pipe, out, str(out_dir / "videos" / e["name"]))
+            if pipe.vae is not None:
+                t1 = time.time()
+                frames = pipe.decode_to_frames(out)
+                torch.cuda.synchronize()
+                dt += time.time() - t1                          # the reference times generate_vc, decode included
+                row["inference_time_s"] = round(dt, 2)
+                row["resolution"] = f"{frames.shape[1]}x{frames.shape[2]}"
+                # run_baseline.py:436-455: its own float64 PSNR (60 dB cap) and skimage-default SSIM, rounded to 4 places
+                m = R.score_generation(frames, blob, e, args, num_frames=num_frames, flavour="baseline")
+                row.update({k: (None if v is None else round(v, 4)) for k, v in m.items()})
+                if args.save_videos:
+                    (out_dir / "videos").mkdir(exist_ok=True)
+                    R.save_frames(pipe, out, str(out_dir / "videos" / e["name"]), frames=frames)
             print(f"  [{idx}] {e['name']}: {dt:.1f}s")
         except Exception as ex:  # recorded and skipped (run_baseline.py:492-501)
             import traceback
@@ -95,7 +113,7 @@ def main(argv=None):
                                                  "std": round(float(np.std(times)), 2) if times else None,
                                                  "min": round(min(times), 2) if times else None,
                                                  "max": round(max(times), 2) if times else None}},
-            "metrics": {"psnr": {}, "ssim": {}, "lpips": {}},
+            "metrics": {k: _stats([r[k] for r in merged if r.get(k) is not None]) for k in ("psnr", "ssim", "lpips")},
             "runtime": {"backend": "mi355x-hip", "world_size": world},
         }
         with open(out_dir / "summary.json", "w") as f:

@@ -443,3 +443,50 @@ class FusedAdamWClip:
              _ptr(self._norm_coef) if self._have_coef else None, float(g["lr"]), float(g["betas"][0]),
              float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), self.step_count, _stream())
         self._have_coef = False
+
+
+# ------------------------------------------------------ frame evaluation ---
+def gaussian_window11(sigma: float = 1.5):
+    """The 11 normalised fp32 taps torchmetrics builds for SSIM (`_gaussian(kernel_size=11, sigma=1.5)`): evaluated
+    here in fp32 with the same operation order so the weights are the very same floats."""
+    import numpy as np
+    dist = np.arange((1 - 11) / 2, (1 + 11) / 2, 1, dtype=np.float32)
+    gauss = np.exp(-np.power(dist / np.float32(sigma), 2) / np.float32(2)).astype(np.float32)
+    return (gauss / gauss.sum(dtype=np.float32)).astype(np.float32)
+
+
+def frame_metrics(gen: torch.Tensor, gt: torch.Tensor, data_range: float = 1.0, ssim: Optional[str] = "gaussian11"):
+    """gen fp32 [N,H,W,C] in [0,1]; gt fp32 or uint8, same shape.  Returns per-frame (mse fp64 [N], ssim fp64 [N] or None)
+    on the host: one launch each, the partial sums added in fp64.  `ssim`: "gaussian11" (torchmetrics defaults),
+    "uniform7" (skimage defaults) or None."""
+    import ctypes
+    import numpy as np
+    _req(gen, F32, "frame_metrics.gen")
+    if gt.dtype not in (torch.uint8, F32) or not gt.is_cuda:
+        raise _lib.LcvError("frame_metrics.gt: fp32 or uint8 GPU tensor expected")
+    if gen.shape != gt.shape or gen.dim() != 4:
+        raise _lib.LcvError(f"frame_metrics: [N,H,W,C] frames of equal shape expected, got {tuple(gen.shape)} / {tuple(gt.shape)}")
+    if ssim not in (None, "gaussian11", "uniform7"):
+        raise _lib.LcvError(f"frame_metrics: unknown ssim variant {ssim!r}")
+    gen, gt = gen.contiguous(), gt.contiguous()
+    N, H, W, C = gen.shape
+    win = 7 if ssim == "uniform7" else 11
+    if ssim is not None and (H < win or W < win):
+        raise _lib.LcvError(f"frame_metrics: a {H}x{W} frame is smaller than the window ({win}x{win})")
+    n_sq, n_ss = ctypes.c_int64(0), ctypes.c_int64(0)
+    call("lcv_frame_metric_partials", H, W, C, win, ctypes.byref(n_sq), ctypes.byref(n_ss))
+    u8 = 1 if gt.dtype == torch.uint8 else 0
+    part = torch.empty((N, n_sq.value), dtype=F32, device=gen.device)
+    call("lcv_frame_sqerr", _ptr(gen), _ptr(gt), u8, _ptr(part), N, H * W * C, _stream())
+    mse = part.double().sum(1).cpu() / float(H * W * C)
+    out = None
+    if ssim is not None:
+        if ssim == "gaussian11":
+            taps, cov_norm, clamp = gaussian_window11(), 1.0, 1
+        else:
+            taps, cov_norm, clamp = np.full(7, 1.0 / 7.0, dtype=np.float32), 49.0 / 48.0, 0
+        spart = torch.empty((N, n_ss.value), dtype=F32, device=gen.device)
+        call("lcv_frame_ssim", _ptr(gen), _ptr(gt), u8, _ptr(spart), N, H, W, C, taps.ctypes.data, win, cov_norm, clamp,
+             (0.01 * data_range) ** 2, (0.03 * data_range) ** 2, _stream())
+        out = spart.double().sum(1).cpu() / float((H - win + 1) * (W - win + 1) * C)
+    return mse, out

@@ -159,14 +159,19 @@ class LongCatVideoPipeline:
             negative_embeds, negative_mask = self.encode_prompt(negative_prompt or "")
         return prompt_embeds, prompt_mask, negative_embeds, negative_mask
 
-    def _decode_to_numpy(self, latents: torch.Tensor) -> np.ndarray:
+    def decode_to_frames(self, latents: torch.Tensor) -> torch.Tensor:
+        """Normalised latents -> fp32 frames [N,H,W,3] in [0,1] ON THE DEVICE (what `generate_*` return after `.cpu()`);
+        the on-device evaluation (tta/eval_metrics.py) reads them in place."""
         vae = self.vae
         mean = torch.tensor(vae.config.latents_mean, device=latents.device, dtype=torch.float32).view(1, -1, 1, 1, 1)
         std = torch.tensor(vae.config.latents_std, device=latents.device, dtype=torch.float32).view(1, -1, 1, 1, 1)
         z = (latents * std + mean).to(vae.dtype)
         video = vae.decode(z, return_dict=False)[0]  # [B,3,N,H,W] in [-1,1]
         video = ((video.float() + 1.0) / 2.0).clamp(0, 1)
-        return video[0].permute(1, 2, 3, 0).cpu().numpy()
+        return video[0].permute(1, 2, 3, 0).contiguous()
+
+    def _decode_to_numpy(self, latents: torch.Tensor) -> np.ndarray:
+        return self.decode_to_frames(latents).cpu().numpy()
 
     @torch.no_grad()
     def generate_vc(self, video, prompt: Optional[str] = None, negative_prompt: Optional[str] = None,

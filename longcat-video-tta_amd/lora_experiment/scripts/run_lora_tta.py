@@ -37,6 +37,8 @@ from tta import cli_args as C  # noqa: E402
 from tta.early_stopping import add_early_stopping_args, build_early_stopper_from_args  # noqa: E402
 from tta.inner_loop import choose_gradient_checkpointing, finetune_lora_on_conditioning  # noqa: E402
 from tta.latent_split import _estimate_latent_len, num_frames_valid, split_tta_latents  # noqa: E402
+from tta.runner_common import (list_eval_entries, load_components, load_entry, save_frames,  # noqa: E402,F401
+                               score_generation)
 from tta.lora import (count_lora_parameters, get_lora_parameters, inject_lora_into_dit, reset_lora_weights,  # noqa: E402
                       save_lora_weights)
 
@@ -83,66 +85,6 @@ def build_parser():
     C.add_online_eval_args(p)
     C.add_clip_gate_args(p)
     return p
-
-
-def load_components(args, device):
-    from longcat_video.modules.longcat_video_dit import LongCatVideoTransformer3DModel
-    from longcat_video.modules.scheduling_flow_match_euler_discrete import FlowMatchEulerDiscreteScheduler
-    from longcat_video.pipeline_longcat_video import LongCatVideoPipeline
-    ck = args.checkpoint_dir
-    if ck.startswith("synthetic"):
-        kw = {}
-        if ":" in ck:  # synthetic:depth[:hidden] — reduced sizes are for plumbing tests only
-            parts = ck.split(":")[1:]
-            kw["depth"] = int(parts[0])
-            if len(parts) > 1:
-                kw.update(hidden_size=int(parts[1]), num_heads=int(parts[1]) // 128)
-            if len(parts) > 2:
-                kw.update(caption_channels=int(parts[2]))
-        dit = LongCatVideoTransformer3DModel(device=device, dtype=torch.bfloat16, **kw).init_synthetic_(1234)
-        sched, vae = FlowMatchEulerDiscreteScheduler(), None
-    else:
-        dit = LongCatVideoTransformer3DModel.from_pretrained(ck, subfolder="dit", cp_split_hw=[1, 1],
-                                                             enable_flashattn2=True, torch_dtype=torch.bfloat16).to(device)
-        sched = FlowMatchEulerDiscreteScheduler.from_pretrained(ck, subfolder="scheduler")
-        from longcat_video.modules.autoencoder_kl_wan import AutoencoderKLWan
-        vae = AutoencoderKLWan.from_pretrained(ck, subfolder="vae", torch_dtype=torch.bfloat16).to(device)
-    pipe = LongCatVideoPipeline(vae=vae, scheduler=sched, dit=dit)
-    pipe.device = torch.device(device)
-    return dit, pipe
-
-
-def list_eval_entries(args, dit):
-    d = args.data_dir
-    if d.startswith("synthetic"):
-        n = int(d.split(":")[1]) if ":" in d else 4
-        return [{"kind": "synthetic", "name": f"synthetic_{i:04d}", "path": f"synthetic://{i}", "seed": 1000 + i}
-                for i in range(min(n, args.max_videos))]
-    lat = Path(d) / "latents"
-    if lat.is_dir():
-        files = sorted(lat.glob("*.pt"))[: args.max_videos]
-        return [{"kind": "latents", "name": f.stem, "path": str(f)} for f in files]
-    vids = sorted(p for p in Path(d).rglob("*") if p.suffix.lower() in (".mp4", ".avi", ".mkv"))[: args.max_videos]
-    return [{"kind": "video", "name": v.stem, "path": str(v)} for v in vids]
-
-
-def load_entry(entry, args, dit, device):
-    h, w = {"480p": (60, 104), "720p": (90, 160)}[args.resolution]
-    if entry["kind"] == "synthetic":
-        T = _estimate_latent_len(args.tta_total_frames)
-        g = torch.Generator(device=device).manual_seed(entry["seed"])
-        cy = dit.config.caption_channels
-        lat = torch.randn((1, dit.config.in_channels, T, h, w), generator=g, device=device).to(torch.bfloat16)
-        pe = torch.randn((1, 1, 512, cy), generator=g, device=device).to(torch.bfloat16)
-        pm = torch.zeros((1, 512), dtype=torch.int64, device=device); pm[:, :77] = 1
-        return dict(latents=lat, prompt_embeds=pe, prompt_mask=pm, negative_embeds=torch.zeros_like(pe), negative_mask=pm,
-                    caption="synthetic")
-    if entry["kind"] == "latents":
-        blob = torch.load(entry["path"], map_location=device)
-        blob.setdefault("caption", "")
-        return blob
-    raise NotImplementedError("raw-video input needs the PyAV decode + VAE-encode + UMT5 rows that precede the hot path "
-                              "(SURVEY §8(f)); pre-encode to <data-dir>/latents/*.pt")
 
 
 def main(argv=None):
@@ -254,13 +196,15 @@ def main(argv=None):
                                    blob.get("negative_mask"), num_cond_latents=ncl,
                                    num_inference_steps=args.num_inference_steps, guidance_scale=args.guidance_scale,
                                    use_kv_cache=True)
-                if pipe.vae is not None and not args.no_save_videos:
-                    frames = pipe._decode_to_numpy(out)
-                    np.save(os.path.join(videos_dir, f"{e['name']}_lora.npy"), (frames * 255).astype(np.uint8))
-                    result["output_path"] = os.path.join(videos_dir, f"{e['name']}_lora.npy")
+                frames = pipe.decode_to_frames(out) if pipe.vae is not None else None
                 torch.cuda.synchronize()
                 gen_time = time.time() - t0
                 result["gen_time"] = gen_time
+                if frames is not None:
+                    result.update(score_generation(frames, blob, e, args))     # run_lora_tta.py:1233-1243
+                    if not args.no_save_videos:
+                        result["output_path"] = save_frames(pipe, out, os.path.join(videos_dir, f"{e['name']}_lora"),
+                                                            frames=frames)
             result["total_time"] = tr["train_time"] + gen_time
             if args.save_lora_weights:
                 save_lora_weights(lora_modules, os.path.join(lora_dir, f"{e['name']}_lora.pt"))
@@ -291,6 +235,8 @@ def main(argv=None):
                        [r["final_loss"] for r in ok if r.get("final_loss") is not None]),
                    "clip_gate_enabled": False, "clip_gate_stats": {"skip_rate": 0.0, "num_skipped": 0, "num_scored": 0},
                    "results": merged}
+        from tta.eval_metrics import aggregate_quality_metrics
+        aggregate_quality_metrics(summary)                                     # run_lora_tta.py:1315 (common.py:2453-2458)
         dp.write_checkpoint(args.output_dir, dp.contiguous_next_idx(merged), merged)
         with open(os.path.join(args.output_dir, "summary.json"), "w") as f:
             json.dump(summary, f, indent=2, default=str)

@@ -74,7 +74,8 @@ def load_components(args, device):
             if len(parts) > 2:
                 kw.update(caption_channels=int(parts[2]))
         dit = LongCatVideoTransformer3DModel(device=device, dtype=torch.bfloat16, **kw).init_synthetic_(1234)
-        sched, vae = FlowMatchEulerDiscreteScheduler(), None
+        from longcat_video.modules.autoencoder_kl_wan import AutoencoderKLWan
+        sched, vae = FlowMatchEulerDiscreteScheduler(), AutoencoderKLWan(device=device).init_synthetic_()
     else:
         dit = LongCatVideoTransformer3DModel.from_pretrained(ck, subfolder="dit", cp_split_hw=[1, 1],
                                                              enable_flashattn2=True, torch_dtype=torch.bfloat16).to(device)
@@ -137,10 +138,35 @@ def generate_continuation(pipe, blob, args, idx, device, num_frames=None):
     return out, time.time() - t0
 
 
-def save_frames(pipe, latents, path_noext: str):
-    frames = pipe._decode_to_numpy(latents)
-    np.save(path_noext + ".npy", (frames * 255).astype(np.uint8))
+def save_frames(pipe, latents, path_noext: str, frames: torch.Tensor = None):
+    frames = pipe.decode_to_frames(latents) if frames is None else frames
+    np.save(path_noext + ".npy", (frames * 255).to(torch.uint8).cpu().numpy())
     return path_noext + ".npy"
+
+
+def ground_truth_frames(blob, entry, shape, device):
+    """uint8 [n, H, W, 3] ground truth of the generated frames at the output resolution: `gt_frames` of a pre-encoded
+    entry (the PyAV decode + LANCZOS resize of common.py:698-715 happen when the entry is prepared), seeded noise for a
+    synthetic one (plumbing: the numbers mean nothing, the path is the real one)."""
+    gt = blob.get("gt_frames")
+    if gt is not None:
+        return torch.as_tensor(gt).to(device)
+    if entry["kind"] == "synthetic":
+        g = torch.Generator(device=device).manual_seed(entry["seed"] + 7919)
+        return torch.randint(0, 256, tuple(shape), generator=g, device=device, dtype=torch.uint8)
+    return None
+
+
+def score_generation(frames: torch.Tensor, blob, entry, args, num_frames=None, flavour: str = "tta") -> Dict:
+    """PSNR / SSIM / LPIPS of the generated frames against the ground truth, on the device (common.py:1233-1243)."""
+    from tta.eval_metrics import evaluate_generation_metrics
+    num_gen = (num_frames if num_frames is not None else args.num_frames) - args.num_cond_frames
+    n_have = max(0, min(num_gen, frames.shape[0] - args.num_cond_frames))
+    gt = ground_truth_frames(blob, entry, (n_have,) + tuple(frames.shape[1:]), frames.device)
+    if gt is None or n_have == 0:
+        return {"psnr": None, "ssim": None, "lpips": None}
+    m = evaluate_generation_metrics(frames, gt, args.num_cond_frames, num_gen, flavour=flavour)
+    return {k: (None if v != v else v) for k, v in m.items()}     # NaN (no LPIPS network offline) -> null in the JSON
 
 
 def clip_gate_summary(args) -> Dict:
@@ -214,9 +240,16 @@ def run_delta_method(args, method: str, make_wrapper: Callable, optimize_fn: Cal
                     out, gen_time = generate_continuation(pipe, blob, args, idx, device)
                 finally:
                     wrapper.remove_from_dit()
+                if pipe.vae is not None:
+                    t1 = time.time()
+                    frames = pipe.decode_to_frames(out)
+                    torch.cuda.synchronize()
+                    gen_time += time.time() - t1              # the reference's gen_time includes the decode (generate_vc)
+                    result.update(score_generation(frames, blob, e, args))
+                    if not args.no_save_videos:
+                        result["output_path"] = save_frames(pipe, out, os.path.join(videos_dir, f"{e['name']}_{file_suffix}"),
+                                                            frames=frames)
                 result["gen_time"] = gen_time
-                if pipe.vae is not None and not args.no_save_videos:
-                    result["output_path"] = save_frames(pipe, out, os.path.join(videos_dir, f"{e['name']}_{file_suffix}"))
             result["total_time"] = train_time + gen_time
             print(f"  [{idx}] {e['name']}: train {train_time:.1f}s loss {result['final_loss']}"
                   + (f" gen {gen_time:.1f}s" if not args.skip_generation else ""))
@@ -246,6 +279,8 @@ def run_delta_method(args, method: str, make_wrapper: Callable, optimize_fn: Cal
         if hasattr(args, "clip_gate_enabled"):
             summary.update(clip_gate_summary(args))
         summary["results"] = merged
+        from tta.eval_metrics import aggregate_quality_metrics
+        aggregate_quality_metrics(summary)
         dp.write_checkpoint(args.output_dir, dp.contiguous_next_idx(merged), merged)
         with open(os.path.join(args.output_dir, "summary.json"), "w") as f:
             json.dump(summary, f, indent=2, default=str)

@@ -76,3 +76,23 @@ if which in ("all","elem"):
     ms=timeit(lambda: ops.gate_residual(x,y,mod,2,T)); print(f"gate_residual: {ms:.3f} ms {3*N*C*2/ms/1e6:.0f} GB/s")
     qkv=torch.randn(1,N,3,32,128,device=dev,dtype=bf); w=torch.ones(128,device=dev,dtype=bf); cs=torch.randn(N,64,2,device=dev)
     ms=timeit(lambda: ops.qknorm_rope(qkv[:,:,0],qkv[:,:,1],None,qkv[:,:,0],qkv[:,:,1],None,w,w,cs)); print(f"qknorm_rope: {ms:.3f} ms {4*N*C*2/ms/1e6:.0f} GB/s")
+if which in ("eval",):
+    # on-device evaluation kernels at the frame sizes of the two resolutions (HBM-bound: 4 B gen + 1 B uint8 gt per element)
+    import ctypes
+    from lcv_hip.lib import call
+    for (N, H, W) in ((14, 480, 832), (36, 720, 1280)):
+        gen = torch.rand(N, H, W, 3, device=dev); gt = torch.randint(0, 256, (N, H, W, 3), device=dev, dtype=torch.uint8)
+        for win in (11, 7):
+            a, b = ctypes.c_int64(0), ctypes.c_int64(0)
+            call("lcv_frame_metric_partials", H, W, 3, win, ctypes.byref(a), ctypes.byref(b))
+            p1 = torch.empty(N, a.value, device=dev); p2 = torch.empty(N, b.value, device=dev)
+            taps = ops.gaussian_window11() if win == 11 else __import__("numpy").full(7, 1 / 7, dtype="float32")
+            st = torch.cuda.current_stream().cuda_stream
+            f1 = lambda: call("lcv_frame_sqerr", gen.data_ptr(), gt.data_ptr(), 1, p1.data_ptr(), N, H * W * 3, st)
+            f2 = lambda: call("lcv_frame_ssim", gen.data_ptr(), gt.data_ptr(), 1, p2.data_ptr(), N, H, W, 3, taps.ctypes.data, win,
+                              1.0, 1, 1e-4, 9e-4, st)
+            by = N * H * W * 3 * 5
+            m1, m2 = timeit(f1, n=20, warm=3), timeit(f2, n=20, warm=3)
+            print(f"eval {N}x{H}x{W} win {win}: sqerr {m1*1e3:.1f} us {by/m1/1e6:.0f} GB/s | ssim {m2*1e3:.1f} us {by/m2/1e6:.0f} GB/s", flush=True)
+        full = lambda: ops.frame_metrics(gen, gt)
+        print(f"  frame_metrics end to end (2 launches + partial sums + D2H): {timeit(full, n=10, warm=2)*1e3:.1f} us", flush=True)

@@ -31,6 +31,9 @@ def test_runner_end_to_end(tmp_path):
         assert r["success"] and {"idx", "video_name", "train_time", "gen_time", "total_time", "final_loss",
                                  "num_train_steps", "early_stopping_info", "es_check_time"} <= set(r)
         assert r["early_stopping_info"]["total_checks"] >= 2 and 1 <= r["num_train_steps"] <= 6
+        # on-device evaluation of the decoded continuation: the keys export_all_results.py:168-171 reads
+        assert 0 < r["psnr"] < 50 and -1 <= r["ssim"] <= 1 and r["lpips"] is None and r["output_path"].endswith("_lora.npy")
+    assert s["psnr"] == pytest.approx(sum(r["psnr"] for r in s["results"]) / 3, abs=1e-5) and s["lpips"] is None
     assert len(list((out / "lora_weights").glob("*_lora.pt"))) == 3
     # resume: nothing left to do, results preserved
     m.main(argv)
@@ -64,8 +67,9 @@ def test_delta_runners_end_to_end(tmp_path, rel, method, extra, key):
     assert s["method"] == method and s["num_videos"] == 2 and s["num_successful"] == 2 and not (out / "config.json").exists()
     assert {"avg_train_time", "avg_es_check_time", "avg_gen_time", "avg_total_time"} <= set(s)
     assert ("clip_gate_enabled" in s) == (method not in ("film_adapter", "norm_tune"))
+    assert s["psnr"] is not None and s["ssim"] is not None
     for r in s["results"]:
-        assert r["success"] and key in r and r["gen_time"] > 0 and r["final_loss"] is not None
+        assert r["success"] and key in r and r["gen_time"] > 0 and r["final_loss"] is not None and r["psnr"] > 0
         assert r["early_stopping_info"]["total_checks"] >= 1
     norms = [sum(r[key]) if isinstance(r[key], list) else r[key] for r in s["results"]]
     assert all(n > 0 for n in norms)                      # the delta moved: gradients reach it through the frozen DiT
@@ -82,6 +86,8 @@ def test_baseline_runner_end_to_end(tmp_path):
     # the shape export_all_results.py:132-166 recognises as the no-TTA baseline
     assert "metrics" in s and "results" not in s and s["num_successful"] == 2 and s["num_frames_total"] == 13
     assert s["timing"]["per_video_inference_s"]["mean"] is not None
+    assert set(s["metrics"]["psnr"]) == {"mean", "std", "min", "max"} and s["metrics"]["ssim"]["mean"] is not None
+    assert s["metrics"]["lpips"] == {}
     assert (out / "per_video_metrics.csv").read_text().splitlines()[0].startswith("index,filename,caption,psnr")
 
 
