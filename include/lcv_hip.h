@@ -291,6 +291,22 @@ int lcv_frame_ssim(const float* gen, const void* gt, int gt_is_u8, float* partia
                    int64_t C, const float* window /* host pointer, `win` normalised taps */, int win, float cov_norm,
                    int clamp_var, float c1, float c2, void* stream);
 
+/* ---- UMT5 text encoder ------------------------------------------------------------------------
+ * The non-GEMM pieces of transformers.UMT5EncoderModel, which the reference runs once per prompt
+ * (delta_experiment/scripts/common.py:62-64, 228-255); the linears go through lcv_gemm_nt.
+ * lcv_gather_rows: out[r, :] = table[ids[r], :] (bf16 rows of C).
+ * lcv_t5_rmsnorm: y = bf16(w * bf16(x * rsqrt(mean(x^2) + eps))) — T5LayerNorm: fp32 statistics, no mean, no bias.
+ * lcv_geglu_tanh_fwd: out = bf16(bf16(gelu_new(gate)) * up), rows x F, inputs with row stride ld_in.
+ * lcv_t5_attention: out[b, i, h*64:(h+1)*64] = softmax_j(q_i.k_j + bias_by_dist[h, j - i + S - 1] + mask_j) . v_j with
+ * d_kv = 64 and NO 1/sqrt(d) scaling; q/k/v are bf16 views with row stride ld_qkv and batch stride bs_qkv (e.g. the three
+ * column blocks of one fused projection), key_mask int32 [B, S] (1 = attend), S <= 512. */
+int lcv_gather_rows(const void* table, const int64_t* ids, void* out, int64_t n, int64_t C, int64_t vocab, void* stream);
+int lcv_t5_rmsnorm(const void* x, const void* w, void* y, int64_t rows, int64_t C, float eps, void* stream);
+int lcv_geglu_tanh_fwd(const void* gate, const void* up, void* out, int64_t rows, int64_t F, int64_t ld_in, void* stream);
+int lcv_t5_attention(const void* q, const void* k, const void* v, void* out, const float* bias_by_dist,
+                     const int* key_mask, int64_t B, int64_t S, int64_t H, int64_t ld_qkv, int64_t ld_o, int64_t bs_qkv,
+                     int64_t bs_o, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -45,6 +45,10 @@ _SIGNATURES = {
     "lcv_conv3d_strided": [P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I, I, I, I, I, I, I64, I64, I64, P],
     "lcv_vae_rmsnorm_silu": [P, P, P, I64, I64, I64, I, P],
     "lcv_softmax_rows": [P, P, I64, I64, I64, I64, F32, P],
+    "lcv_gather_rows": [P, P, P, I64, I64, I64, P],
+    "lcv_t5_rmsnorm": [P, P, P, I64, I64, F32, P],
+    "lcv_geglu_tanh_fwd": [P, P, P, I64, I64, I64, P],
+    "lcv_t5_attention": [P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, P],
     "lcv_frame_metric_partials": [I64, I64, I64, I, P, P],
     "lcv_frame_sqerr": [P, P, I, P, I64, I64, P],
     "lcv_frame_ssim": [P, P, I, P, I64, I64, I64, I64, P, I, F32, I, F32, F32, P],

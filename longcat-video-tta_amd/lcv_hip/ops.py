@@ -490,3 +490,51 @@ def frame_metrics(gen: torch.Tensor, gt: torch.Tensor, data_range: float = 1.0, 
              (0.01 * data_range) ** 2, (0.03 * data_range) ** 2, _stream())
         out = spart.double().sum(1).cpu() / float((H - win + 1) * (W - win + 1) * C)
     return mse, out
+
+
+# ------------------------------------------------------- UMT5 text encoder ---
+def gather_rows(table: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
+    _req(table, BF16, "gather_rows.table")
+    if ids.dtype != torch.int64 or not ids.is_cuda:
+        raise _lib.LcvError("gather_rows.ids: int64 GPU tensor expected")
+    ids = ids.contiguous().view(-1)
+    V, C = table.shape
+    out = torch.empty((ids.numel(), C), dtype=BF16, device=table.device)
+    call("lcv_gather_rows", _ptr(table.contiguous()), _ptr(ids), _ptr(out), ids.numel(), C, V, _stream())
+    return out
+
+
+def t5_rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:
+    _req(x, BF16, "t5_rmsnorm.x"); _req(w, BF16, "t5_rmsnorm.w")
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    C = x.shape[-1]
+    call("lcv_t5_rmsnorm", _ptr(x), _ptr(w.contiguous()), _ptr(y), x.numel() // C, C, eps, _stream())
+    return y
+
+
+def geglu_tanh(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
+    _req(gate, BF16, "geglu_tanh.gate"); _req(up, BF16, "geglu_tanh.up")
+    rows, F = gate.shape
+    if gate.stride(0) != up.stride(0) or gate.stride(1) != 1 or up.stride(1) != 1:
+        raise _lib.LcvError("geglu_tanh: gate/up must share the row stride")
+    out = torch.empty((rows, F), dtype=BF16, device=gate.device)
+    call("lcv_geglu_tanh_fwd", _ptr(gate), _ptr(up), _ptr(out), rows, F, gate.stride(0), _stream())
+    return out
+
+
+def t5_attention(qkv: torch.Tensor, H: int, bias_by_dist: torch.Tensor, key_mask: torch.Tensor) -> torch.Tensor:
+    """qkv bf16 [B, S, 3*H*64] (q | k | v column blocks); bias_by_dist fp32 [H, 2S-1]; key_mask int32 [B, S].
+    Returns [B, S, H*64] bf16."""
+    _req(qkv, BF16, "t5_attention.qkv"); _req(bias_by_dist, F32, "t5_attention.bias")
+    B, S, W3 = qkv.shape
+    inner = H * 64
+    if W3 != 3 * inner or qkv.stride(2) != 1:
+        raise _lib.LcvError(f"t5_attention: qkv last dim {W3} != 3*{H}*64")
+    if tuple(bias_by_dist.shape) != (H, 2 * S - 1) or key_mask.dtype != torch.int32 or tuple(key_mask.shape) != (B, S):
+        raise _lib.LcvError("t5_attention: bias_by_dist [H, 2S-1] fp32 and key_mask [B, S] int32 expected")
+    out = torch.empty((B, S, inner), dtype=BF16, device=qkv.device)
+    base = qkv.data_ptr()
+    call("lcv_t5_attention", base, base + inner * 2, base + 2 * inner * 2, _ptr(out), _ptr(bias_by_dist.contiguous()),
+         _ptr(key_mask.contiguous()), B, S, H, qkv.stride(1), inner, qkv.stride(0), S * inner, _stream())
+    return out

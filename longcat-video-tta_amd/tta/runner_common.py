@@ -82,7 +82,14 @@ def load_components(args, device):
         sched = FlowMatchEulerDiscreteScheduler.from_pretrained(ck, subfolder="scheduler")
         from longcat_video.modules.autoencoder_kl_wan import AutoencoderKLWan
         vae = AutoencoderKLWan.from_pretrained(ck, subfolder="vae", torch_dtype=torch.bfloat16).to(device)
-    pipe = LongCatVideoPipeline(vae=vae, scheduler=sched, dit=dit)
+    tokenizer = text_encoder = None
+    if not ck.startswith("synthetic") and os.path.isdir(os.path.join(ck, "text_encoder")):
+        # common.py:59-64: AutoTokenizer (host-side SentencePiece, from transformers) + the UMT5 encoder, here on the HIP kernels
+        from longcat_video.modules.umt5_encoder import UMT5EncoderModel
+        text_encoder = UMT5EncoderModel.from_pretrained(ck, subfolder="text_encoder", torch_dtype=torch.bfloat16).to(device)
+        from transformers import AutoTokenizer
+        tokenizer = AutoTokenizer.from_pretrained(ck, subfolder="tokenizer")
+    pipe = LongCatVideoPipeline(tokenizer=tokenizer, text_encoder=text_encoder, vae=vae, scheduler=sched, dit=dit)
     pipe.device = torch.device(device)
     return dit, pipe
 
