@@ -2,8 +2,8 @@
 """Norm-tuning TTA (unfreeze the cross-attention pre-norm affine and / or the q/k RMS-norm weights) on MI355X — same relative
 path, CLI flags and artifact schemas as the reference's `delta_experiment/scripts/run_norm_tune_tta.py` (flags :292-319 — no
 CLIP-gate group; summary :631-655).  The tuned weights live in the DiT for the video's continuation and are restored before the
-next video.  `--also-tune-delta` (a delta-A vector in the same optimizer) is parsed but not built: the fused clip + AdamW takes
-one dtype per parameter list (bf16 norms vs the fp32 delta)."""
+next video.  `--also-tune-delta` (:380-391) adds a delta-A vector (fp32) on the t_embedder output to the same optimizer: one fused
+AdamW per dtype, tied by a joint clip coefficient (`FusedAdamWClip.joint_clip_grad_norm_`)."""
 import argparse
 import sys
 from pathlib import Path
@@ -30,17 +30,14 @@ def build_parser():
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
-    if args.also_tune_delta:
-        raise NotImplementedError("--also-tune-delta mixes an fp32 delta with bf16 norm weights in one optimizer; run "
-                                  "run_delta_a.py and run_norm_tune_tta.py separately")
     R.run_delta_method(
         args, "norm_tune",
-        make_wrapper=lambda dit: NormTuneForward(dit, args.norm_target),
+        make_wrapper=lambda dit: NormTuneForward(dit, args.norm_target, also_tune_delta=args.also_tune_delta),
         optimize_fn=lambda w, cond, train, pe, pm, device, es: optimize_norm_params(
             w, cond, train, pe, pm, num_steps=args.norm_steps, lr=args.norm_lr, device=device, dtype=torch.bfloat16,
             early_stopper=es),
-        params_of=lambda w: w.norm_params,
-        result_extra=lambda opt: {"norm_param_drift": opt["norm_param_drift"]},
+        params_of=lambda w: w.tuned_params,
+        result_extra=lambda opt: {k: opt[k] for k in ("norm_param_drift", "delta_norm") if k in opt},
         summary_head={"norm_target": args.norm_target, "norm_steps": args.norm_steps, "norm_lr": args.norm_lr},
         file_suffix="norm_tune", cleanup=lambda w: w.restore())
 

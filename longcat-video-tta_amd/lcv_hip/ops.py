@@ -435,6 +435,27 @@ class FusedAdamWClip:
         self._have_coef = True
         return self._norm_coef[0]
 
+    @staticmethod
+    def joint_clip_grad_norm_(opts, max_norm: float) -> float:
+        """ONE clip over several optimizers' parameters (a bf16 list and an fp32 list under the same
+        `clip_grad_norm_(all_params, max_norm)`): per-tensor norms in each tensor's own dtype, the total over their fp32
+        stack, coefficient min(max_norm / (total + 1e-6), 1) — torch's rule for mixed dtypes.  Reads the per-tensor
+        squares back (one sync per step); used only by the norm + delta tuning option."""
+        total_sq = 0.0
+        live = [o for o in opts if any(p.grad is not None for p in o.params)]
+        for o in live:
+            o.clip_grad_norm_(max_norm)                       # fills o._ws with the per-tensor sums of squares
+            sq = o._ws[:o._n_active].sqrt()
+            if not o.f32:
+                sq = sq.to(BF16).to(F32)                      # a bf16 tensor's norm is a bf16 number
+            total_sq += float((sq * sq).sum().item())
+        total = total_sq ** 0.5
+        coef = min(max_norm / (total + 1e-6), 1.0)
+        for o in live:
+            o._norm_coef[0] = total
+            o._norm_coef[1] = coef
+        return total
+
     def step(self):
         d = self._descriptors()
         g = self.param_groups[0]

@@ -190,7 +190,16 @@ class FiLMAdapterWrapper(_HookedWrapper):
 
 def _optimize(wrapper: nn.Module, params: List[nn.Parameter], per_param_clip: bool, cond_latents, train_latents,
               prompt_embeds, prompt_mask, num_steps, lr, device, dtype, early_stopper, train_latents_variants):
-    groups = [[p] for p in params] if per_param_clip else [params]
+    joint = False
+    if per_param_clip:
+        groups = [[p] for p in params]
+    elif len({p.dtype for p in params}) > 1:
+        # one AdamW + one clip over bf16 and fp32 parameters together (norm weights + a delta vector): one fused optimizer
+        # per dtype, tied by a joint clip coefficient
+        groups = [[p for p in params if p.dtype == dt] for dt in (torch.bfloat16, torch.float32)]
+        joint = True
+    else:
+        groups = [params]
     opts = [FusedAdamWClip(g, lr=lr, betas=(0.9, 0.999), weight_decay=0.01, eps=1e-15) for g in groups]
     if train_latents_variants is None:
         train_latents_variants = [{"latents": train_latents, "name": "orig"}]
@@ -209,9 +218,12 @@ def _optimize(wrapper: nn.Module, params: List[nn.Parameter], per_param_clip: bo
                                                       prompt_embeds=prompt_embeds, prompt_mask=prompt_mask,
                                                       device=device, dtype=dtype)
         loss.backward()
+        if joint:
+            FusedAdamWClip.joint_clip_grad_norm_(opts, 1.0)
         for o in opts:
             if any(p.grad is not None for p in o.params):
-                o.clip_grad_norm_(1.0)
+                if not joint:
+                    o.clip_grad_norm_(1.0)
                 o.step()
         losses.append(loss.item())
         if early_stopper is not None:
@@ -300,7 +312,7 @@ class NormTuneForward(nn.Module):
     `remove_from_dit` exist so the shared runner loop can treat it like the hook-based wrappers (the tuned weights are in
     the modules already; `restore()` puts the per-job originals back for the next video)."""
 
-    def __init__(self, dit: nn.Module, norm_target: str = "all_norm"):
+    def __init__(self, dit: nn.Module, norm_target: str = "all_norm", also_tune_delta: bool = False):
         super().__init__()
         self.dit = dit
         for p in dit.parameters():
@@ -309,6 +321,20 @@ class NormTuneForward(nn.Module):
         for p in self.norm_params:
             p.requires_grad = True
         self._orig = [p.data.clone() for p in self.norm_params]
+        # --also-tune-delta (run_norm_tune_tta.py:380-391): a delta-A vector (fp32, like the reference's
+        # nn.Parameter(torch.zeros(adaln_dim))) added to the t_embedder output by a forward hook and tuned in the SAME
+        # optimizer; the hook stays for the video's continuation and goes away in restore()
+        self.delta = None
+        self._delta_hook = None
+        if also_tune_delta:
+            dev = next(dit.parameters()).device
+            self.delta = nn.Parameter(torch.zeros(dit.config.adaln_tembed_dim, device=dev))
+            delta = self.delta
+            self._delta_hook = dit.t_embedder.register_forward_hook(lambda _m, _i, out: out + delta.unsqueeze(0).to(out.dtype))
+
+    @property
+    def tuned_params(self):
+        return self.norm_params + ([self.delta] if self.delta is not None else [])
 
     @property
     def config(self):
@@ -325,6 +351,9 @@ class NormTuneForward(nn.Module):
             p.data.copy_(o)
             p.requires_grad = False
             p.grad = None
+        if self._delta_hook is not None:
+            self._delta_hook.remove()
+            self._delta_hook = None
 
     def forward(self, hidden_states, timestep, encoder_hidden_states, encoder_attention_mask=None, num_cond_latents=0, **kw):
         return self.dit(hidden_states=hidden_states, timestep=timestep, encoder_hidden_states=encoder_hidden_states,
@@ -336,7 +365,10 @@ def optimize_norm_params(wrapper: NormTuneForward, cond_latents, train_latents, 
                          early_stopper: Optional[AnchoredEarlyStopper] = None,
                          train_latents_variants: Optional[List[Dict]] = None) -> Dict:
     """run_norm_tune_tta.py:215-283: AdamW(eps 1e-15) over the norm parameters (bf16, like the module), global clip 1.0."""
-    losses, est, es_state = _optimize(wrapper, wrapper.norm_params, False, cond_latents, train_latents, prompt_embeds,
+    losses, est, es_state = _optimize(wrapper, wrapper.tuned_params, False, cond_latents, train_latents, prompt_embeds,
                                       prompt_mask, num_steps, lr, device, dtype, early_stopper, train_latents_variants)
     drift = sum((p.detach().float() - o.float()).norm().item() for p, o in zip(wrapper.norm_params, wrapper._orig))
-    return {"losses": losses, "norm_param_drift": drift, "es_check_time": est, "early_stopping_info": es_state}
+    out = {"losses": losses, "norm_param_drift": drift, "es_check_time": est, "early_stopping_info": es_state}
+    if wrapper.delta is not None:
+        out["delta_norm"] = wrapper.delta.detach().norm().item()
+    return out

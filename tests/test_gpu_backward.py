@@ -422,3 +422,32 @@ def test_qk_norm_weight_gradients():
         worst = max(worst, e)
         assert e < 6e-2, (n, e)
     print("norm-weight gradient rel-L2 (max over 12 tensors):", worst)
+
+
+def test_joint_clip_over_bf16_and_fp32_parameters_matches_torch():
+    """`--also-tune-delta`: torch runs ONE clip_grad_norm_ + ONE AdamW over bf16 norm weights and an fp32 delta
+    (run_norm_tune_tta.py:230, 258-259).  Here: one fused optimizer per dtype tied by the joint coefficient."""
+    from lcv_hip.ops import FusedAdamWClip
+    g = torch.Generator().manual_seed(21)
+    shapes = [(128,), (4096,), (128,)]
+    p16 = [torch.randn(s, generator=g).to(BF16) for s in shapes]
+    p32 = [torch.randn(512, generator=g) * 0.1]
+    ref = [torch.nn.Parameter(p.clone()) for p in p16 + p32]
+    ropt = torch.optim.AdamW(ref, lr=1e-2, betas=(0.9, 0.999), eps=1e-15)
+    mine = [torch.nn.Parameter(p.clone().to(DEV)) for p in p16 + p32]
+    opts = [FusedAdamWClip(mine[:3], lr=1e-2, weight_decay=0.01, eps=1e-15), FusedAdamWClip(mine[3:], lr=1e-2, weight_decay=0.01, eps=1e-15)]
+    for step in range(4):
+        scale = 5.0 if step % 2 == 0 else 0.01                     # clipped and unclipped steps
+        grads = [(torch.randn(p.shape, generator=g) * scale).to(p.dtype) for p in ref]
+        for p, q, gr in zip(ref, mine, grads):
+            p.grad = gr.clone(); q.grad = gr.clone().to(DEV)
+        tn = torch.nn.utils.clip_grad_norm_(ref, 1.0)
+        ropt.step()
+        total = FusedAdamWClip.joint_clip_grad_norm_(opts, 1.0)
+        for o in opts:
+            o.step()
+        assert abs(total - tn.item()) <= 4e-3 * tn.item()          # bf16 per-tensor norms on both sides
+        for p, q in zip(ref, mine):
+            d = (q.detach().cpu().float() - p.detach().float()).abs()
+            ulp = p.detach().float().abs() * (2 ** -7 if p.dtype == BF16 else 2 ** -20) + 1e-6
+            assert (d <= 2 * ulp).all(), (step, d.max())

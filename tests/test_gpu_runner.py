@@ -55,6 +55,9 @@ def _run(rel, argv):
                                                                   "--film-mode", "shift_scale"], "correction_norm"),
     ("delta_experiment/scripts/run_norm_tune_tta.py", "norm_tune", ["--norm-steps", "4", "--norm-lr", "1e-2", "--norm-target",
                                                                     "all_norm"], "norm_param_drift"),
+    # norm weights (bf16) + a delta-A vector (fp32) in one optimizer under one clip (run_norm_tune_tta.py:380-391)
+    ("delta_experiment/scripts/run_norm_tune_tta.py", "norm_tune", ["--norm-steps", "4", "--norm-lr", "1e-2", "--norm-target",
+                                                                    "qk_norm", "--also-tune-delta"], "delta_norm"),
 ])
 def test_delta_runners_end_to_end(tmp_path, rel, method, extra, key):
     """delta wrapper -> anchored ES -> optimise -> hooks installed for the KV-cached continuation -> reference schemas."""
