@@ -163,6 +163,41 @@ def measure_reference_point(dit, dev, pe, pm, ne, nm) -> dict:
     return out
 
 
+def measure_full_tta_reference_point(dit, dev, pe, pm) -> dict:
+    """Full-model TTA at the same operating point (SGD, 5 steps -> 24.0 s on 1x H200,
+    experimental_report.md:182-184): all 13.6 B parameters trainable, block checkpointing on, fused clip + SGD.
+    Runs LAST: it moves the weights."""
+    import functools
+    import gc
+    from torch.utils.checkpoint import checkpoint
+    from lcv_hip import autograd_ops
+    from tta.full_tta import finetune_full_on_conditioning
+    autograd_ops.clear_weight_caches()                      # the LoRA legs' resident W^T copies (27 GB)
+    for b in dit.blocks:
+        b.ffn._w13 = None
+    gc.collect(); torch.cuda.empty_cache()
+    h, w = 60, 104
+    g = torch.Generator(device=dev).manual_seed(13)
+    cond = torch.randn((1, 16, 3, h, w), generator=g, device=dev).to(torch.bfloat16)
+    train = torch.randn((1, 16, 1, h, w), generator=g, device=dev).to(torch.bfloat16)
+    dit.gradient_checkpointing = True
+    dit._gradient_checkpointing_func = functools.partial(checkpoint, use_reentrant=False)
+    for p_ in dit.parameters():
+        p_.requires_grad = True
+    kw = dict(lr=1e-5, warmup_steps=2, device=str(dev), dtype=torch.bfloat16, optimizer_type="sgd")
+    finetune_full_on_conditioning(dit, cond, train, pe, pm, num_steps=1, **kw)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    res = finetune_full_on_conditioning(dit, cond, train, pe, pm, num_steps=5, **kw)
+    torch.cuda.synchronize()
+    out = {"full_tta5_s": time.perf_counter() - t0, "full_tta5_s_reference_h200": 24.0,
+           "full_tta_losses": [round(x, 4) for x in res["losses"]]}
+    for p_ in dit.parameters():
+        p_.requires_grad = False
+        p_.grad = None
+    dit.gradient_checkpointing = False
+    return out
+
+
 def measure_extras(dit, dev, T, h, w, pe, pm) -> dict:
     """VAE decode of the finished clip and the LoRA-TTA inner-loop step (lora_experiment config: r=8, alpha 16,
     qkv+proj on all 48 blocks, Tc=4 clean + Tt=3 noised latent frames at the bench resolution)."""
@@ -283,6 +318,7 @@ def main():
         with contextlib.redirect_stdout(sys.stderr):   # stdout carries exactly one JSON line
             ref_point = measure_reference_point(dit, dev, pe, pm, ne, nm)
             extras = measure_extras(dit, dev, T, h, w, pe, pm)
+            ref_point.update(measure_full_tta_reference_point(dit, dev, pe, pm))
         extras["reference_operating_point_480p_14c14g"] = {k: (round(v, 2) if isinstance(v, float) else v) for k, v in ref_point.items()}
         extras["wall_clock_per_tta_video_s_extrapolated"] = (
             20 * extras["tta_step_s"] + args.num_inference_steps * sec_per_step + extras["vae_decode_s"])

@@ -251,6 +251,26 @@ int lcv_adamw_step(const lcv_adam_tensor* tensors, int64_t n_tensors, int64_t to
                    const float* norm_coef, double lr, double beta1, double beta2, double eps, double weight_decay,
                    int64_t step, void* stream);
 
+/* torch.optim.SGD(momentum=0, weight_decay) after clip_grad_norm_, foreach op order and bf16 rounding points:
+ * g = g*coef; g += wd*p; p -= lr*g.  Same descriptor table as AdamW (moment pointers unused).  The default optimizer
+ * of full-model TTA: lora_experiment/scripts/run_full_tta.py:138-144, 179-180. */
+int lcv_sgd_step(const lcv_adam_tensor* tensors, int64_t n_tensors, int64_t total_chunks, int param_f32,
+                 const float* norm_coef, double lr, double weight_decay, void* stream);
+
+/* ---- dense backward pieces of full-model TTA (run_full_tta.py:95-215: loss.backward() over ALL DiT parameters) ----
+ * lcv_transpose_pad: out[N, Mpad] = in[M, N]^T (row stride ld), columns >= M zero, Mpad % 64 == 0.  With it a dense
+ *   weight gradient dW[N,K] = dY^T . X is lcv_gemm_nt(A = dY^T [N, Mpad], W = X^T [K, Mpad]).
+ * lcv_rowsum: out[r] = sum_c in[r, c] (bias gradient from dY^T); out bf16 or fp32.
+ * lcv_linear_f32_smallm_wgrad: weight / bias gradients of the fp32-island linears (adaLN modulation, timestep MLP):
+ *   dw[n,k] = sum_m dy[m,n] act(a[m,k]), db[n] = sum_m dy[m,n], bf16 outputs, act_in as lcv_linear_f32_smallm.
+ * lcv_gelu_tanh_fwd / _bwd: the caption embedder's activation when its linears are trainable (unfused form). */
+int lcv_transpose_pad(const void* in, void* out, int64_t M, int64_t N, int64_t ld, int64_t Mpad, void* stream);
+int lcv_rowsum(const void* in, void* out, int64_t rows, int64_t cols, int out_f32, void* stream);
+int lcv_linear_f32_smallm_wgrad(const float* dy, const float* a, void* dw, void* db, int64_t M, int64_t N, int64_t K,
+                                int act_in, void* stream);
+int lcv_gelu_tanh_fwd(const void* x, void* y, int64_t n, void* stream);
+int lcv_gelu_tanh_bwd(const void* x, const void* dy, void* dx, int64_t n, void* stream);
+
 /* ---- VAE stages (WAN-style causal 3-D conv VAE; upstream AutoencoderKLWan.decode / .encode, contract at
  * delta_experiment/scripts/common.py:209-221) --------------------------------------------------------------- */
 /* Causal conv3d as an implicit GEMM on the MFMA core.  x [B,Tin,Hin,Win,Cin] channels-last bf16 (Cin % 64 == 0,

@@ -161,3 +161,49 @@ extern "C" int lcv_adamw_step(const lcv_adam_tensor* tensors, int64_t n_tensors,
   LCV_LAUNCH_CHECK("adamw_step");
   return LCV_OK;
 }
+
+// ---------------------------------------------------------------------------
+// SGD (momentum 0) with weight decay, the default optimizer of full-model TTA
+// (lora_experiment/scripts/run_full_tta.py:138-144: SGD(params, lr, momentum=0.0, weight_decay)), in the op order
+// and bf16 rounding points of torch.optim.SGD's foreach path after clip_grad_norm_:
+//   g = bf16(g * coef);  g = bf16(g + wd * p);  p = bf16(p - lr * g)
+// Same descriptor table as AdamW (exp_avg / exp_avg_sq unused).  8 B / parameter read, 2 written.
+// ---------------------------------------------------------------------------
+template <bool F32>
+__global__ __launch_bounds__(256) void sgd_kernel(const lcv_adam_tensor* __restrict__ tensors, int n,
+                                                  const float* __restrict__ clip, float lr, float wd) {
+  const int ti = find_tensor(tensors, n, blockIdx.x);
+  const lcv_adam_tensor t = tensors[ti];
+  const int64_t base = ((int64_t)blockIdx.x - t.first_chunk) * CHUNK + threadIdx.x * 8;
+  const float coef = clip ? clip[1] : 1.0f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int64_t i = base + e;
+    if (i >= t.numel) break;
+    if (F32) {
+      float* P = (float*)t.param;
+      float g = __fmul_rn(((const float*)t.grad)[i], coef);
+      g = __fadd_rn(g, __fmul_rn(wd, P[i]));
+      P[i] = __fadd_rn(P[i], __fmul_rn(-lr, g));
+    } else {
+      bf16_t* P = (bf16_t*)t.param;
+      const float p = bf2f(P[i]);
+      float g = bfround(__fmul_rn(bf2f(((const bf16_t*)t.grad)[i]), coef));
+      if (wd != 0.f) g = bfround(__fadd_rn(g, __fmul_rn(wd, p)));
+      P[i] = f2bf(__fadd_rn(p, __fmul_rn(-lr, g)));
+    }
+  }
+}
+
+extern "C" int lcv_sgd_step(const lcv_adam_tensor* tensors, int64_t n_tensors, int64_t total_chunks, int param_f32,
+                            const float* norm_coef, double lr, double weight_decay, void* stream) {
+  LCV_CHECK_ARG(tensors && n_tensors > 0 && total_chunks > 0 && total_chunks <= 0x7fffffff, "sgd_step: bad arguments");
+  if (param_f32)
+    hipLaunchKernelGGL(sgd_kernel<true>, dim3((unsigned)total_chunks), dim3(256), 0, (hipStream_t)stream, tensors, (int)n_tensors,
+                       norm_coef, (float)lr, (float)weight_decay);
+  else
+    hipLaunchKernelGGL(sgd_kernel<false>, dim3((unsigned)total_chunks), dim3(256), 0, (hipStream_t)stream, tensors, (int)n_tensors,
+                       norm_coef, (float)lr, (float)weight_decay);
+  LCV_LAUNCH_CHECK("sgd_step");
+  return LCV_OK;
+}

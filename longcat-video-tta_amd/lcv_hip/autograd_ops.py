@@ -42,6 +42,30 @@ def transposed_weight(w: torch.Tensor) -> torch.Tensor:
 
 def clear_weight_caches():
     _WT_CACHE.clear()
+    _XT_LAST.clear()
+
+
+# full-model TTA: the token-major input of a trainable linear, transposed for the dense weight gradient.  Linears that
+# share their input (w1 / w3) run back to back in the backward, so the last transpose is kept.
+_XT_LAST = {}
+
+
+def _transposed_input(x: torch.Tensor) -> torch.Tensor:
+    key = (x.data_ptr(), x._version, tuple(x.shape))
+    ent = _XT_LAST.get("x")
+    if ent is not None and ent[0] == key:
+        return ent[1]
+    xt = ops.transpose_pad(x)
+    _XT_LAST["x"] = (key, xt)
+    return xt
+
+
+def _dense_param_grads(x2: torch.Tensor, dyb: torch.Tensor, want_dw: bool, want_db: bool, w_dtype, b_dtype):
+    """(dW [N,K], db [N]) of y = x W^T + b from x [M,K] and dy [M,N] (run_full_tta.py: every weight is trainable)."""
+    dyT = ops.transpose_pad(dyb)
+    dw = ops.dense_wgrad(dyT, _transposed_input(x2)).to(w_dtype) if want_dw else None
+    db = ops.rowsum(dyT).to(b_dtype) if want_db else None
+    return dw, db
 
 
 # --------------------------------------------------------------------------- linear
@@ -56,8 +80,9 @@ class _LinearFn(torch.autograd.Function):
     def forward(ctx, x, w, b, epi, out_f32):
         ctx.save_for_backward(x if w.requires_grad else None, w)
         ctx.out_f32 = out_f32
+        ctx.b_dtype = b.dtype if b is not None else None
         if epi != LCV_EPI_NONE:
-            raise LcvError("linear: fused activation epilogues have no backward (embedders are frozen inputs)")
+            raise LcvError("linear: fused activation epilogues have no backward (use the unfused form when training)")
         return ops.gemm_nt(x, w, b, epilogue=epi, out_f32=out_f32)
 
     @staticmethod
@@ -67,19 +92,17 @@ class _LinearFn(torch.autograd.Function):
         N, K = w.shape
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = ops.gemm_nt(dyb, transposed_weight(w), None)
-        if w.requires_grad:
-            # trainable weights are only supported for skinny (adapter-sized) linears: the frozen 13.6 B base never
-            # gets a dW on this path (LoRA-only backward)
-            if N <= 32:
-                dw = ops.tn_skinny(_pad_cols(dyb), x, N).to(w.dtype)
-            elif K <= 32:
-                dw = ops.tn_skinny(_pad_cols(x), dyb, K).t().contiguous().to(w.dtype)
-            else:
-                raise LcvError("linear: weight gradients of full-size linears are out of scope (LoRA-only backward); "
-                               "freeze the base weight")
-        if ctx.needs_input_grad[2]:
-            raise LcvError("linear: bias gradients are out of scope; freeze the bias")
+            # a frozen base weight keeps a resident W^T (LoRA TTA); a trainable one changes every step, so its
+            # transpose is a temporary
+            wt = w.detach().t().contiguous() if w.requires_grad else transposed_weight(w)
+            dx = ops.gemm_nt(dyb, wt, None)
+        want_db = ctx.needs_input_grad[2]
+        if w.requires_grad and N <= 32 and not want_db:          # adapter-sized: the skinny kernels
+            dw = ops.tn_skinny(_pad_cols(dyb), x, N).to(w.dtype)
+        elif w.requires_grad and K <= 32 and not want_db:
+            dw = ops.tn_skinny(_pad_cols(x), dyb, K).t().contiguous().to(w.dtype)
+        elif w.requires_grad or want_db:                          # dense weights / biases: full-model TTA
+            dw, db = _dense_param_grads(x if w.requires_grad else None, dyb, w.requires_grad, want_db, w.dtype, ctx.b_dtype)
         return dx, dw, db, None, None
 
 
@@ -99,15 +122,19 @@ class _LinearF32Fn(torch.autograd.Function):
     def forward(ctx, a, w, b, act_in):
         ctx.save_for_backward(a, w)
         ctx.act_in = act_in
+        ctx.b_dtype = b.dtype if b is not None else None
         return ops.linear_f32_smallm(a, w, b, act_in)
 
     @staticmethod
     def backward(ctx, dy):
         a, w = ctx.saved_tensors
-        if w.requires_grad:
-            raise LcvError("linear_f32: weight gradients are out of scope")
-        da = ops.linear_f32_smallm_bwd(dy.contiguous(), w, a, ctx.act_in)
-        return da, None, None, None
+        dw = db = None
+        if w.requires_grad or ctx.needs_input_grad[2]:            # full-model TTA: adaLN modulation / timestep MLP weights
+            dw, db = ops.linear_f32_smallm_wgrad(dy.contiguous().float(), a, ctx.act_in, ctx.needs_input_grad[2])
+            dw = dw.to(w.dtype) if w.requires_grad else None
+            db = db.to(ctx.b_dtype) if db is not None else None
+        da = ops.linear_f32_smallm_bwd(dy.contiguous(), w, a, ctx.act_in) if ctx.needs_input_grad[0] else None
+        return da, dw, db, None
 
 
 def linear_f32(a: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], act_in: int = 0) -> torch.Tensor:
@@ -443,6 +470,25 @@ def cross_attention(q, kv, wq, wk, seqlens: List[int], scale, eps):
     return o
 
 
+# --------------------------------------------------------------------------- GELU (caption embedder, trainable form)
+class _GeluTanhFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return ops.gelu_tanh(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops.gelu_tanh_bwd(x, (dy if dy.dtype == BF16 else dy.to(BF16)).contiguous())
+
+
+def gelu_tanh(x: torch.Tensor) -> torch.Tensor:
+    if _needs_grad(x):
+        return _GeluTanhFn.apply(x)
+    return ops.gelu_tanh(x)
+
+
 # --------------------------------------------------------------------------- SwiGLU
 class _SwiGLUFn(torch.autograd.Function):
     @staticmethod
@@ -469,10 +515,39 @@ def swiglu_fused(x2: torch.Tensor, w13: torch.Tensor) -> torch.Tensor:
 
 
 # --------------------------------------------------------------------------- patch embed / unpatchify
+class _PatchEmbedFn(torch.autograd.Function):
+    """Trainable x_embedder (full-model TTA): the latent input never needs a gradient, the conv weight / bias do."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        B, C = x.shape[0], w.shape[0]
+        kin = w[0].numel()
+        kpad = ((kin + 63) // 64) * 64
+        w2 = w.reshape(C, kin)
+        if kpad != kin:
+            w2 = torch.nn.functional.pad(w2, (0, kpad - kin))
+        tok = ops.patchify(x if x.dtype == BF16 else x.to(BF16), kpad).view(-1, kpad)
+        ctx.save_for_backward(tok)
+        ctx.meta = (tuple(w.shape), kin, w.dtype, b.dtype if b is not None else None, w.requires_grad)
+        return ops.gemm_nt(tok, w2.contiguous(), b).view(B, -1, C)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (tok,) = ctx.saved_tensors
+        wshape, kin, wdt, bdt, wreq = ctx.meta
+        dyb = dy.reshape(-1, dy.shape[-1])
+        dyb = (dyb if dyb.dtype == BF16 else dyb.to(BF16)).contiguous()
+        dw2, db = _dense_param_grads(tok, dyb, wreq, ctx.needs_input_grad[2], wdt, bdt)
+        dw = dw2[:, :kin].reshape(wshape).contiguous() if dw2 is not None else None
+        return None, dw, db
+
+
 def patch_embed(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """x [B,Cin,T,H,W] -> [B, N, C]: patchify (k = c*4 + ph*2 + pw) + GEMM with the flattened conv weight."""
-    if _needs_grad(x, w, b):
-        raise LcvError("patch_embed: gradients w.r.t. the latent input or x_embedder are out of scope")
+    if _needs_grad(x):
+        raise LcvError("patch_embed: gradients w.r.t. the latent input are out of scope")
+    if _needs_grad(w, b):
+        return _PatchEmbedFn.apply(x, w, b)
     B = x.shape[0]
     C = w.shape[0]
     kin = w[0].numel()

@@ -41,6 +41,12 @@ _SIGNATURES = {
     "lcv_fm_mse": [P, P, P, P, P, I64, I64, I64, I64, I64, P],
     "lcv_grad_norm_clip": [P, I64, I64, I, F32, P, P, P],
     "lcv_adamw_step": [P, I64, I64, I, P, F64, F64, F64, F64, F64, I64, P],
+    "lcv_sgd_step": [P, I64, I64, I, P, F64, F64, P],
+    "lcv_transpose_pad": [P, P, I64, I64, I64, I64, P],
+    "lcv_rowsum": [P, P, I64, I64, I, P],
+    "lcv_linear_f32_smallm_wgrad": [P, P, P, P, I64, I64, I64, I, P],
+    "lcv_gelu_tanh_fwd": [P, P, I64, P],
+    "lcv_gelu_tanh_bwd": [P, P, P, I64, P],
     "lcv_causal_conv3d": [P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I, I, I, I, P],
     "lcv_conv3d_strided": [P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I, I, I, I, I, I, I64, I64, I64, P],
     "lcv_vae_rmsnorm_silu": [P, P, P, I64, I64, I64, I, P],

@@ -559,3 +559,88 @@ def t5_attention(qkv: torch.Tensor, H: int, bias_by_dist: torch.Tensor, key_mask
     call("lcv_t5_attention", base, base + inner * 2, base + 2 * inner * 2, _ptr(out), _ptr(bias_by_dist.contiguous()),
          _ptr(key_mask.contiguous()), B, S, H, qkv.stride(1), inner, qkv.stride(0), S * inner, _stream())
     return out
+
+
+# ------------------------------------------------ full-model TTA (dense backward) ---
+def transpose_pad(x: torch.Tensor) -> torch.Tensor:
+    """bf16 [M, N] (contiguous rows) -> [N, Mpad] with Mpad = M rounded up to 64, pad columns zero."""
+    _req(x, BF16, "transpose_pad.x")
+    if x.dim() != 2 or x.stride(1) != 1:
+        raise _lib.LcvError("transpose_pad: 2-D tensor with contiguous rows expected")
+    M, N = x.shape
+    Mpad = (M + 63) // 64 * 64
+    out = torch.empty((N, Mpad), dtype=BF16, device=x.device)
+    call("lcv_transpose_pad", _ptr(x), _ptr(out), M, N, x.stride(0), Mpad, _stream())
+    return out
+
+
+def rowsum(xT: torch.Tensor, dtype=BF16) -> torch.Tensor:
+    _req(xT, BF16, "rowsum.x")
+    xT = xT.contiguous()
+    out = torch.empty((xT.shape[0],), dtype=dtype, device=xT.device)
+    call("lcv_rowsum", _ptr(xT), _ptr(out), xT.shape[0], xT.shape[1], 1 if dtype == F32 else 0, _stream())
+    return out
+
+
+def dense_wgrad(dyT: torch.Tensor, xT: torch.Tensor) -> torch.Tensor:
+    """dW [N, K] = dY^T . X from the two transposed, token-padded operands: one NT GEMM over the token axis."""
+    return gemm_nt(dyT, xT, None)
+
+
+def linear_f32_smallm_wgrad(dy: torch.Tensor, a: torch.Tensor, act_in: int, want_db: bool):
+    _req(dy, F32, "linear_f32_smallm_wgrad.dy"); _req(a, F32, "linear_f32_smallm_wgrad.a")
+    dy, a = dy.contiguous(), a.contiguous()
+    M, N = dy.shape
+    K = a.shape[1]
+    dw = torch.empty((N, K), dtype=BF16, device=dy.device)
+    db = torch.empty((N,), dtype=BF16, device=dy.device) if want_db else None
+    call("lcv_linear_f32_smallm_wgrad", _ptr(dy), _ptr(a), _ptr(dw), _ptr(db), M, N, K, act_in, _stream())
+    return dw, db
+
+
+def gelu_tanh(x: torch.Tensor) -> torch.Tensor:
+    _req(x, BF16, "gelu_tanh.x")
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    call("lcv_gelu_tanh_fwd", _ptr(x), _ptr(y), x.numel(), _stream())
+    return y
+
+
+def gelu_tanh_bwd(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+    _req(x, BF16, "gelu_tanh_bwd.x"); _req(dy, BF16, "gelu_tanh_bwd.dy")
+    x, dy = x.contiguous(), dy.contiguous()
+    dx = torch.empty_like(x)
+    call("lcv_gelu_tanh_bwd", _ptr(x), _ptr(dy), _ptr(dx), x.numel(), _stream())
+    return dx
+
+
+class FusedSGDClip(FusedAdamWClip):
+    """clip_grad_norm_ + SGD(momentum=0, weight_decay).step over a parameter list in two launches — the default
+    optimizer of full-model TTA (lora_experiment/scripts/run_full_tta.py:138-144, 179-180).  No optimizer state."""
+
+    def __init__(self, params, lr=1e-5, weight_decay=0.01):
+        self.params = [p for p in params]
+        if not self.params:
+            raise ValueError("optimizer got an empty parameter list")
+        dt = self.params[0].dtype
+        if dt not in (BF16, F32) or any(p.dtype != dt for p in self.params):
+            raise _lib.LcvError("FusedSGDClip: parameters must be all bf16 or all fp32")
+        self.f32 = dt == F32
+        self.param_groups = [dict(params=self.params, lr=lr, weight_decay=weight_decay)]
+        self.exp_avg = self.params            # the descriptor table has moment slots; SGD never reads them
+        self.exp_avg_sq = self.params
+        self.step_count = 0
+        dev = self.params[0].device
+        self._ws = torch.zeros(len(self.params), dtype=F32, device=dev)
+        self._norm_coef = torch.zeros(2, dtype=F32, device=dev)
+        self._desc = None
+        self._desc_key = None
+        self._have_coef = False
+
+    def step(self):
+        d = self._descriptors()
+        g = self.param_groups[0]
+        self.step_count += 1
+        call("lcv_sgd_step", _ptr(d), self._n_active, self._total_chunks, 1 if self.f32 else 0,
+             _ptr(self._norm_coef) if self._have_coef else None, float(g["lr"]), float(g["weight_decay"]), _stream())
+        self._have_coef = False

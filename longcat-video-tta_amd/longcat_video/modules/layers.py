@@ -316,7 +316,11 @@ class CaptionEmbedder(nn.Module):
     def forward(self, caption):
         shp = caption.shape
         x = caption.reshape(-1, shp[-1])
-        h = A.linear(x, self.y_proj[0].weight, self.y_proj[0].bias, epilogue="gelu_tanh")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.y_proj.parameters()):
+            # full-model TTA trains the embedder: the activation is its own differentiable op
+            h = A.gelu_tanh(A.linear(x, self.y_proj[0].weight, self.y_proj[0].bias))
+        else:
+            h = A.linear(x, self.y_proj[0].weight, self.y_proj[0].bias, epilogue="gelu_tanh")
         y = A.linear(h, self.y_proj[2].weight, self.y_proj[2].bias)
         return y.view(*shp[:-1], y.shape[-1])
 

@@ -451,3 +451,82 @@ def test_joint_clip_over_bf16_and_fp32_parameters_matches_torch():
             d = (q.detach().cpu().float() - p.detach().float()).abs()
             ulp = p.detach().float().abs() * (2 ** -7 if p.dtype == BF16 else 2 ** -20) + 1e-6
             assert (d <= 2 * ulp).all(), (step, d.max())
+
+
+@pytest.mark.parametrize("ncond,ckpt", [(1, False), (0, True)])
+def test_full_model_gradients_match_oracle_autograd(ncond, ckpt):
+    """Full-model TTA (lora_experiment/scripts/run_full_tta.py:452-453: every DiT parameter trainable): loss.backward()
+    through the HIP DiT must give EVERY named parameter the gradient torch autograd gives over the fp32 oracle — dense
+    weights (transposes + the NT GEMM over the token axis), biases (row sums of dY^T), the fp32-island linears (adaLN
+    modulation, timestep MLP), the embedders, the final layer and the norm weights."""
+    import functools
+    from torch.utils.checkpoint import checkpoint
+    from oracle import dit_oracle as orc
+    from tta.flow_matching import fm_mse_loss
+    m, cfg, P = _small_dit()
+    for p in m.parameters():
+        p.requires_grad = True
+    if ckpt:
+        m.gradient_checkpointing = True
+        m._gradient_checkpointing_func = functools.partial(checkpoint, use_reentrant=False)
+    m.train()
+    B, T, H, W, L = 1, 3, 8, 8, 16
+    hs = _randn(B, 16, T, H, W, seed=40); y = _randn(B, 1, L, 64, seed=41)
+    mask = torch.zeros(B, L, dtype=torch.int64); mask[:, :11] = 1
+    ts = torch.zeros(B, T); ts[:, ncond:] = 612.0
+    eps = _randn(B, 16, T - ncond, H, W, seed=42); x0 = _randn(B, 16, T - ncond, H, W, seed=43)
+    pred = m(hs.to(DEV), ts.to(BF16).to(DEV), y.to(DEV), mask.to(DEV), num_cond_latents=ncond)
+    loss = fm_mse_loss(pred, eps.to(DEV), x0.to(DEV), ncond)
+    loss.backward()
+    P2 = {k: v.float().clone().requires_grad_(True) for k, v in P.items()}
+    ref = orc.dit_forward(P2, cfg, hs, ts.to(BF16), y, mask, ncond, bf16=False)
+    ref_loss = torch.nn.functional.mse_loss(ref[:, :, ncond:], (eps - x0).float())
+    ref_loss.backward()
+    assert abs(loss.item() - ref_loss.item()) < 2e-2 * abs(ref_loss.item())
+    errs, missing = {}, []
+    for name, p in m.named_parameters():
+        r = P2[name].grad
+        if r is None or float(r.norm()) == 0.0:
+            assert p.grad is None or float(p.grad.float().norm()) < 1e-6, name    # e.g. cross-attn k_norm with no text... never here
+            continue
+        if p.grad is None:
+            missing.append(name)
+            continue
+        assert p.grad.dtype == p.dtype and p.grad.shape == p.shape, name
+        errs[name] = rel_l2(p.grad, r)
+    assert not missing, missing
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:6]
+    print("params with a gradient:", len(errs), "worst:", [(k, round(v, 4)) for k, v in worst])
+    vals = sorted(errs.values())
+    assert vals[-1] < 8e-2 and vals[len(vals) // 2] < 3e-2, worst
+
+
+def test_fused_sgd_clip_matches_torch():
+    """clip_grad_norm_ + torch.optim.SGD(momentum=0, weight_decay) on bf16 tensors (run_full_tta.py:138-144, 179-180)."""
+    from lcv_hip.ops import FusedSGDClip
+    g = torch.Generator().manual_seed(8)
+    shapes = [(300, 70), (4096,), (33,), (2049,)]
+    ref = [torch.nn.Parameter((torch.randn(s, generator=g) * 0.5).to(BF16)) for s in shapes]
+    mine = [torch.nn.Parameter(p.detach().clone().to(DEV)) for p in ref]
+    ropt = torch.optim.SGD(ref, lr=1e-2, momentum=0.0, weight_decay=0.01)
+    opt = FusedSGDClip(mine, lr=1e-2, weight_decay=0.01)
+    for step in range(5):
+        if step < 2:                                   # the reference's linear warm-up writes param_groups[...]["lr"]
+            for o in (ropt, opt):
+                for pg in o.param_groups:
+                    pg["lr"] = 1e-2 * (step + 1) / 2
+        scale = 4.0 if step % 2 == 0 else 0.02
+        for p, q in zip(ref, mine):
+            gr = (torch.randn(p.shape, generator=g) * scale).to(BF16)
+            p.grad = gr.clone(); q.grad = gr.clone().to(DEV)
+        before = [p.detach().float().abs().clone() for p in ref]
+        tn = torch.nn.utils.clip_grad_norm_(ref, 1.0)
+        ropt.step()
+        n = opt.clip_grad_norm_(1.0)
+        opt.step()
+        assert abs(n.item() - tn.item()) <= 2 ** -7 * tn.item()
+        for p, q, b in zip(ref, mine, before):
+            d = (q.detach().cpu().float() - p.detach().float()).abs()
+            # one bf16 ulp of the PRE-update magnitude (an update that nearly cancels leaves a tiny value whose own ulp
+            # says nothing), on a small fraction of the elements (torch holds lr / wd in double, the kernel in fp32)
+            assert (d <= torch.maximum(b, p.detach().float().abs()) * 2 ** -7 + 1e-30).all() and (d > 0).float().mean() < 0.02, (step, d.max())

@@ -106,3 +106,53 @@ def test_no_tta_control_num_steps_zero(tmp_path):
     s = json.loads((out / "summary.json").read_text())
     r = s["results"][0]
     assert s["num_successful"] == 1 and r["num_train_steps"] == 0 and r["final_loss"] is None and r["gen_time"] > 0
+
+
+@pytest.mark.parametrize("optimizer", ["sgd", "adamw"])
+def test_full_tta_runner_end_to_end(tmp_path, optimizer):
+    """Every DiT parameter trainable -> checkpointed backward -> fused clip + SGD / AdamW -> early stopping on the stopper's
+    own snapshot -> continuation -> scoring; reference schemas (run_full_tta.py:466-510, 864-905)."""
+    out = tmp_path / f"full_{optimizer}"
+    _run("lora_experiment/scripts/run_full_tta.py",
+         ["--checkpoint-dir", "synthetic:2:256:64", "--data-dir", "synthetic:2", "--output-dir", str(out), "--num-cond-frames", "5",
+          "--num-frames", "13", "--gen-start-frame", "40", "--tta-total-frames", "33", "--tta-context-frames", "9", "--num-steps", "4",
+          "--learning-rate", "1e-4", "--optimizer", optimizer, "--es-check-every", "2", "--es-patience", "1",
+          "--num-inference-steps", "2", "--no-save-videos"])
+    cfg = json.loads((out / "config.json").read_text())
+    assert cfg["method"] == "full_tta" and cfg["training"]["trainable_params"] == cfg["training"]["total_params"] > 1e6
+    assert cfg["training"]["optimizer"] == optimizer and cfg["clip_gate"]["enabled"] is False
+    s = json.loads((out / "summary.json").read_text())
+    assert s["method"] == "full_tta" and s["num_successful"] == 2 and s["num_failed"] == 0 and s["total_params"] == cfg["training"]["total_params"]
+    assert s["avg_final_loss"] > 0 and s["psnr"] is not None
+    for r in s["results"]:
+        assert r["success"] and 1 <= r["num_train_steps"] <= 4 and r["final_loss"] > 0 and r["gen_time"] > 0 and r["psnr"] > 0
+        assert r["early_stopping_info"]["total_checks"] >= 1
+    assert json.loads((out / "checkpoint.json").read_text())["next_idx"] == 2
+
+
+def test_full_tta_training_moves_the_weights_and_reset_restores_them():
+    import torch
+    from longcat_video.modules.longcat_video_dit import LongCatVideoTransformer3DModel
+    from tta.full_tta import finetune_full_on_conditioning, reset_dit_weights, snapshot_base_state
+    dit = LongCatVideoTransformer3DModel(device="cuda", dtype=torch.bfloat16, depth=2, hidden_size=256, num_heads=2,
+                                         caption_channels=64).init_synthetic_(5)
+    for p in dit.parameters():
+        p.requires_grad = True
+    base = snapshot_base_state(dit)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    lat = torch.randn((1, 16, 4, 16, 16), generator=g, device="cuda").to(torch.bfloat16)
+    pe = torch.randn((1, 1, 32, 64), generator=g, device="cuda").to(torch.bfloat16)
+    pm = torch.ones((1, 32), dtype=torch.int64, device="cuda")
+    tr = finetune_full_on_conditioning(dit, lat[:, :, :2], lat[:, :, 2:], pe, pm, num_steps=3, lr=1e-2, warmup_steps=1,
+                                       max_grad_norm=1.0, optimizer_type="sgd")
+    assert len(tr["losses"]) == 3 and all(l == l for l in tr["losses"])
+    moved = [n for n, p in dit.named_parameters() if not torch.equal(p.detach(), base[n])]
+    # every family of parameters got an update (norm weights sit at 1.0, where a clipped bf16 step is below half an ulp)
+    assert len(moved) >= 0.75 * len(list(dit.named_parameters())), len(moved)
+    for fam in ("x_embedder.proj.weight", "t_embedder.mlp.0.weight", "y_embedder.y_proj.2.weight", "blocks.0.adaLN_modulation.1.weight",
+                "blocks.1.attn.qkv.weight", "blocks.0.attn.proj.bias", "blocks.1.cross_attn.kv_linear.weight", "blocks.0.ffn.w2.weight",
+                "final_layer.linear.weight", "final_layer.adaLN_modulation.1.bias"):
+        assert fam in moved, fam
+    assert all(p.grad is None for p in dit.parameters())                          # gradients released before the continuation
+    reset_dit_weights(dit, base)
+    assert all(torch.equal(p.detach(), base[n]) for n, p in dit.named_parameters())

@@ -117,3 +117,23 @@ def test_baseline_runner_parses_the_reference_flags():
                                      "--num-inference-steps", "50", "--guidance-scale", "4.0", "--seed", "42", "--max-videos",
                                      "100", "--save-videos"])
     assert a.num_gen_frames == 14 and a.resolution == "720p" and a.save_videos
+
+
+def test_full_tta_runner_parses_the_sbatch_flag_set():
+    """METHOD=full: sweep_experiment/sbatch/run_sweep.sbatch:344-372 -> lora_experiment/scripts/run_full_tta.py."""
+    path = ROOT / "longcat-video-tta_amd" / "lora_experiment" / "scripts" / "run_full_tta.py"
+    spec = importlib.util.spec_from_file_location("run_full_tta_amd", path)
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    argv = ["--checkpoint-dir", "/ckpt", "--data-dir", "/data", "--output-dir", "/out", "--max-videos", "100",
+            "--learning-rate", "1e-5", "--num-steps", "10", "--warmup-steps", "2", "--weight-decay", "0.01", "--max-grad-norm", "1.0",
+            "--optimizer", "sgd", "--batch-videos", "1", "--num-cond-frames", "14", "--num-frames", "28", "--gen-start-frame", "32",
+            "--tta-total-frames", "32", "--tta-context-frames", "14", "--num-inference-steps", "50", "--guidance-scale", "4.0",
+            "--resolution", "480p", "--seed", "42", "--es-check-every", "5", "--es-patience", "3", "--es-anchor-sigmas", "0.25,0.5,0.75",
+            "--es-noise-draws", "2", "--es-strategy", "patience", "--es-holdout-fraction", "0.25", "--clip-gate-threshold", "0.0",
+            "--no-save-videos", "--restart"]
+    args = m.build_parser().parse_args(argv)
+    assert args.optimizer == "sgd" and args.learning_rate == 1e-5 and args.num_steps == 10 and args.warmup_steps == 2
+    d = m.build_parser().parse_args(["--checkpoint-dir", "c", "--data-dir", "d", "--output-dir", "o"])
+    assert (d.learning_rate, d.num_steps, d.warmup_steps, d.weight_decay, d.max_grad_norm, d.optimizer) == (1e-5, 10, 2, 0.01, 1.0, "sgd")
+    with pytest.raises(SystemExit):
+        m.build_parser().parse_args(argv + ["--optimizer", "lion"])

@@ -26,6 +26,7 @@ def main(out_root):
     run("lora_experiment/scripts/run_lora_tta.py", common + ["--output-dir", str(sweep / "L1"), "--num-steps", "6", "--lora-rank", "4",
                                                              "--lora-alpha", "8"])
     run("lora_experiment/scripts/run_lora_tta.py", common + ["--output-dir", str(sweep / "L0_no_tta"), "--num-steps", "0", "--es-disable"])
+    run("lora_experiment/scripts/run_full_tta.py", common + ["--output-dir", str(sweep / "F_full1"), "--num-steps", "4", "--learning-rate", "1e-4"])
     run("delta_experiment/scripts/run_delta_a.py", common + ["--output-dir", str(sweep / "DA1"), "--delta-steps", "4"])
     run("delta_experiment/scripts/run_delta_b.py", common + ["--output-dir", str(sweep / "DB1"), "--delta-steps", "4", "--num-groups", "2"])
     run("delta_experiment/scripts/run_delta_c.py", common + ["--output-dir", str(sweep / "DC1"), "--delta-steps", "4"])
