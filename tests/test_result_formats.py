@@ -3,7 +3,7 @@
 tests/golden/result_tree/ is a PROJECT_ROOT-shaped tree written by THIS build's runners on an MI355X
 (tools/make_result_tree.py: every runner on the synthetic 2-block model, 3 videos).  In the build container the
 reference's own sweep_experiment/scripts/export_all_results.py and export_loss_curves.py were pointed at it
-(PROJECT_ROOT=<tree>): 8 complete runs collected, 7 matched to the cond5_gen8 baseline with dPSNR/dSSIM, loss curves
+(PROJECT_ROOT=<tree>): 9 complete runs collected, 8 matched to the cond5_gen8 baseline with dPSNR/dSSIM, loss curves
 extracted for every run with early stopping — see DESIGN.md §2.  Those scripts cannot travel, so this test restates the
 reads they perform (export_all_results.py:104-268, export_loss_curves.py:79-151) and applies them to the same tree."""
 import json
@@ -15,7 +15,7 @@ import pytest
 
 TREE = Path(__file__).resolve().parent / "golden" / "result_tree"
 SERIES = TREE / "sweep_experiment" / "results" / "series_amd_plumbing"
-TTA_RUNS = {"L1": "lora_tta", "L0_no_tta": "lora_tta", "DA1": "delta_a", "DB1": "delta_b", "DC1": "delta_c",
+TTA_RUNS = {"L1": "lora_tta", "L0_no_tta": "lora_tta", "F_full1": "full_tta", "DA1": "delta_a", "DB1": "delta_b", "DC1": "delta_c",
             "F1": "film_adapter", "N1": "norm_tune"}
 
 
@@ -77,6 +77,8 @@ def test_tta_run_is_readable_by_the_exporter(run, method):
         assert rec["final_loss_mean"] > 0 and rec["es_best_step_mean"] >= 0
     if method == "lora_tta":                          # config.json is flattened into the record (:231-245)
         assert rec["rank"] in (4, 8) and rec["trainable_params"] > 0 and rec["implementation"] == "custom"
+    if method == "full_tta":
+        assert rec["trainable_params"] == rec["total_params"] > 1e6 and rec["optimizer"] == "sgd" and rec["num_steps"] == 4
     if method in ("film_adapter", "norm_tune"):
         assert "clip_gate_enabled" not in rec         # those two runners do not add the CLIP-gate group
     else:
@@ -94,7 +96,7 @@ def test_baseline_run_is_recognised_and_matched():
     assert head == "index,filename,caption,psnr,ssim,lpips,resolution,inference_time_s"
 
 
-@pytest.mark.parametrize("run", ["L1", "DA1", "DB1", "DC1", "F1", "N1"])
+@pytest.mark.parametrize("run", ["L1", "F_full1", "DA1", "DB1", "DC1", "F1", "N1"])
 def test_loss_curves_are_extractable(run):
     """export_loss_curves.py:79-151: loss_history [[step, loss], ...] per video, aggregated per step; it also takes the
     mean PSNR of the run (and raises when no video has one — the reason the runners score every generation)."""
