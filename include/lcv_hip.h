@@ -102,9 +102,10 @@ int lcv_qknorm_rope_fwd(const void* q_in, const void* k_in, const void* v_in,
                         int64_t pos_off, float eps, float q_scale, void* stream);
 /* Backward: given dq_out, dk_out (same addressing as q_out/k_out) and the
  * pre-norm q_in/k_in, writes dq_in, dk_in (strides din_*); q_scale as in the forward.  dwq / dwk
- * (nullable, fp32 [128], ACCUMULATED into by atomics - zero them first) receive the gradients of the
- * two norm weights (norm-weight tuning, delta_experiment/scripts/run_norm_tune_tta.py:87-98); the dq
- * share is w.r.t. the weight as it enters the forward, i.e. it carries q_scale. */
+ * (nullable, fp32 [dw_slots, 128], ACCUMULATED into by atomics - zero them first; token n adds into row
+ * n % dw_slots, the caller sums the rows) receive the gradients of the two norm weights (norm-weight tuning,
+ * delta_experiment/scripts/run_norm_tune_tta.py:87-98; full-model TTA); the dq share is w.r.t. the weight as it
+ * enters the forward, i.e. it carries q_scale. */
 int lcv_qknorm_rope_bwd(const void* q_in, const void* k_in,
                         const void* dq_out, const void* dk_out,
                         void* dq_in, void* dk_in,
@@ -114,7 +115,7 @@ int lcv_qknorm_rope_bwd(const void* q_in, const void* k_in,
                         int64_t q_sb, int64_t q_sn,
                         int64_t kv_sb, int64_t kv_sn,
                         int64_t din_sb, int64_t din_sn,
-                        int64_t pos_off, float eps, float q_scale, float* dwq, float* dwk, void* stream);
+                        int64_t pos_off, float eps, float q_scale, float* dwq, float* dwk, int64_t dw_slots, void* stream);
 
 /* ---- flash attention (dense, non-causal, head_dim 128, bf16, fp32 acc) */
 /* o[b,n,h,:] = softmax(q k^T * scale) v ; q: Nq rows, k/v: Nk rows.
@@ -241,7 +242,8 @@ typedef struct {
   int64_t first_chunk;
 } lcv_adam_tensor;
 /* torch.nn.utils.clip_grad_norm_: per-tensor norms (rounded to the grad dtype) -> total norm -> coefficient
- * min(max_norm / (total + 1e-6), 1).  per_tensor_ws: fp32 [n_tensors]; norm_coef_out: fp32 [2] = {norm, coef}.
+ * min(max_norm / (total + 1e-6), 1).  per_tensor_ws: fp32 [n_tensors, 64] (64 partial sums of squares per tensor);
+ * norm_coef_out: fp32 [2] = {norm, coef}.
  * lora_experiment/scripts/run_lora_tta.py:513. */
 int lcv_grad_norm_clip(const lcv_adam_tensor* tensors, int64_t n_tensors, int64_t total_chunks, int param_f32,
                        float max_norm, float* per_tensor_ws, float* norm_coef_out, void* stream);

@@ -12,14 +12,28 @@
 //   MODE 1 (affine): y = xh*w+b            ; g = dy*w         ; db += dy     ; dw += dy*xh
 //   dx = rstd * (g - mean(g) - xh * mean(g*xh))
 // ---------------------------------------------------------------------------
+// Rows per workgroup when the parameter / modulation gradients are wanted: each wave walks ROWNORM_RPB/4 rows and the
+// per-channel sums of the whole workgroup are kept in LDS (ds_add_f32), so the global fp32 atomics are one per channel per
+// ROWNORM_RPB rows instead of one per channel per row (51 M -> 1.6 M per call at 6 240 tokens: the kernel was atomic-bound).
+#define ROWNORM_RPB 32
+
 template <int MODE>
 __global__ __launch_bounds__(256) void rownorm_bwd_kernel(
     const bf16_t* __restrict__ x, const float* __restrict__ p_mul, const bf16_t* __restrict__ dy,
     bf16_t* __restrict__ dx, float* __restrict__ d_add, float* __restrict__ d_mul, int64_t rows, int C,
-    int64_t S, int64_t mod_stride, float eps) {
+    int64_t S, int64_t mod_stride, float eps, int rows_per_block) {
+  __shared__ float s_add[ROWNORM_MAXCH * 64 * 8], s_mul[ROWNORM_MAXCH * 64 * 8];
   const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
+  const bool want_d = d_add != nullptr;
+  const int64_t row0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t frame0 = (MODE == 0) ? row0 / S : 0;          // the frame the LDS sums belong to
+  if (want_d) {
+    for (int i = threadIdx.x; i < C; i += 256) { s_add[i] = 0.f; s_mul[i] = 0.f; }
+    __syncthreads();
+  }
+  for (int it = 0; it < rows_per_block; it += 4) {
+    const int64_t row = row0 + it + (threadIdx.x >> 6);
+    if (row >= rows) continue;
   const bf16_t* xr = x + row * C;
   const bf16_t* gr = dy + row * C;
   const int64_t frame = (MODE == 0) ? row / S : 0;
@@ -54,6 +68,7 @@ __global__ __launch_bounds__(256) void rownorm_bwd_kernel(
   }
   const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
   float sg = 0.f, sgx = 0.f;
+  const bool in_lds = frame == frame0;      // a workgroup that straddles two frames sends the second one's rows directly
 #pragma unroll
   for (int ch = 0; ch < ROWNORM_MAXCH; ++ch) {
     const int c = (ch * 64 + lane) * 8;
@@ -64,9 +79,14 @@ __global__ __launch_bounds__(256) void rownorm_bwd_kernel(
       for (int i = 0; i < 8; ++i) {
         const float xh = (v[ch][i] - mean) * rstd;
         const float dyv = g[ch][i];
-        if (d_add) {  // parameter / modulation gradients (fp32 atomics, 32-byte runs per lane)
-          atomicAdd(d_add + frame * mod_stride + c + i, dyv);
-          atomicAdd(d_mul + frame * mod_stride + c + i, dyv * xh);
+        if (want_d) {  // parameter / modulation gradients
+          if (in_lds) {
+            atomicAdd(&s_add[c + i], dyv);
+            atomicAdd(&s_mul[c + i], dyv * xh);
+          } else {
+            atomicAdd(d_add + frame * mod_stride + c + i, dyv);
+            atomicAdd(d_mul + frame * mod_stride + c + i, dyv * xh);
+          }
         }
         const float mul = ((i < 4) ? m0[i] : m1[i - 4]) + ((MODE == 0) ? 1.0f : 0.0f);
         const float gg = dyv * mul;
@@ -90,6 +110,14 @@ __global__ __launch_bounds__(256) void rownorm_bwd_kernel(
       *reinterpret_cast<u16x8*>(dr + c) = pack8(o);
     }
   }
+  }
+  if (want_d) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < C; i += 256) {
+      atomicAdd(d_add + frame0 * mod_stride + i, s_add[i]);
+      atomicAdd(d_mul + frame0 * mod_stride + i, s_mul[i]);
+    }
+  }
 }
 
 extern "C" int lcv_adaln_modulate_bwd(const void* x, const float* mod, const void* dy, void* dx, float* dmod,
@@ -99,10 +127,11 @@ extern "C" int lcv_adaln_modulate_bwd(const void* x, const float* mod, const voi
   LCV_CHECK_ARG(C > 0 && C % 8 == 0 && C <= 4096, "adaln_modulate_bwd: C must be a multiple of 8 and <= 4096");
   const int64_t rows = B * T * S;
   if (rows == 0) return LCV_OK;
-  hipLaunchKernelGGL(rownorm_bwd_kernel<0>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+  const int rpb = dmod ? ROWNORM_RPB : 4;
+  hipLaunchKernelGGL(rownorm_bwd_kernel<0>, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)x, mod + scale_off, (const bf16_t*)dy, (bf16_t*)dx,
                      dmod ? dmod + shift_off : nullptr, dmod ? dmod + scale_off : nullptr, rows, (int)C, S,
-                     mod_stride, eps);
+                     mod_stride, eps, rpb);
   LCV_LAUNCH_CHECK("adaln_modulate_bwd");
   return LCV_OK;
 }
@@ -113,9 +142,10 @@ extern "C" int lcv_layernorm_affine_bwd(const void* x, const float* w, const voi
   LCV_CHECK_ARG((dw == nullptr) == (db == nullptr), "layernorm_affine_bwd: dw and db go together");
   LCV_CHECK_ARG(C > 0 && C % 8 == 0 && C <= 4096, "layernorm_affine_bwd: C must be a multiple of 8 and <= 4096");
   if (rows == 0) return LCV_OK;
-  hipLaunchKernelGGL(rownorm_bwd_kernel<1>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+  const int rpb = dw ? ROWNORM_RPB : 4;
+  hipLaunchKernelGGL(rownorm_bwd_kernel<1>, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)x, w, (const bf16_t*)dy, (bf16_t*)dx, db, dw, rows, (int)C, (int64_t)1,
-                     (int64_t)0, eps);
+                     (int64_t)0, eps, rpb);
   LCV_LAUNCH_CHECK("layernorm_affine_bwd");
   return LCV_OK;
 }
@@ -150,6 +180,63 @@ __global__ __launch_bounds__(256) void gate_residual_bwd_kernel(const bf16_t* __
   }
 }
 
+// dgate wanted: a workgroup owns GATE_RPB consecutive rows; thread t owns the same 8-channel packets (t, t+256, ...) in
+// every row, so the per-channel products accumulate in registers and reach memory as one atomic per channel per
+// GATE_RPB rows (flushed early when the rows cross into the next frame).
+#define GATE_RPB 32
+#define GATE_MAXPK 2   // C <= 4096: 512 packets per row over 256 threads
+__global__ __launch_bounds__(256) void gate_residual_bwd_dgate_kernel(const bf16_t* __restrict__ y, const float* __restrict__ gate,
+                                                                      const bf16_t* __restrict__ dout, bf16_t* __restrict__ dy,
+                                                                      float* __restrict__ dgate, int64_t rows, int cpk, int64_t S,
+                                                                      int64_t mod_stride) {
+  const int64_t row0 = (int64_t)blockIdx.x * GATE_RPB;
+  float acc[GATE_MAXPK][8];
+#pragma unroll
+  for (int u = 0; u < GATE_MAXPK; ++u)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[u][i] = 0.f;
+  int64_t cur_frame = row0 / S;
+  auto flush = [&](int64_t frame) {
+#pragma unroll
+    for (int u = 0; u < GATE_MAXPK; ++u) {
+      const int pkc = threadIdx.x + u * 256;
+      if (pkc < cpk) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          atomicAdd(dgate + frame * mod_stride + pkc * 8 + i, acc[u][i]);
+          acc[u][i] = 0.f;
+        }
+      }
+    }
+  };
+  for (int r = 0; r < GATE_RPB; ++r) {
+    const int64_t row = row0 + r;
+    if (row >= rows) break;
+    const int64_t frame = row / S;
+    if (frame != cur_frame) { flush(cur_frame); cur_frame = frame; }
+#pragma unroll
+    for (int u = 0; u < GATE_MAXPK; ++u) {
+      const int pkc = threadIdx.x + u * 256;
+      if (pkc < cpk) {
+        const int64_t pk = row * cpk + pkc;
+        const int64_t goff = frame * mod_stride + pkc * 8;
+        float d[8], o[8], yf[8];
+        unpack8(*reinterpret_cast<const u16x8*>(dout + pk * 8), d);
+        unpack8(*reinterpret_cast<const u16x8*>(y + pk * 8), yf);
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gate + goff);
+        const f32x4 g1 = *reinterpret_cast<const f32x4*>(gate + goff + 4);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          o[i] = d[i] * ((i < 4) ? g0[i] : g1[i - 4]);
+          acc[u][i] = fmaf(d[i], yf[i], acc[u][i]);
+        }
+        *reinterpret_cast<u16x8*>(dy + pk * 8) = pack8(o);
+      }
+    }
+  }
+  flush(cur_frame);
+}
+
 extern "C" int lcv_gate_residual_bwd(const void* y, const float* mod, const void* dout, void* dy, float* dmod,
                                      int64_t B, int64_t T, int64_t S, int64_t C, int64_t mod_stride,
                                      int64_t gate_off, void* stream) {
@@ -157,6 +244,14 @@ extern "C" int lcv_gate_residual_bwd(const void* y, const float* mod, const void
   LCV_CHECK_ARG(C % 8 == 0 && gate_off % 4 == 0 && mod_stride % 4 == 0, "gate_residual_bwd: bad alignment");
   const int64_t n_packets = B * T * S * (C / 8);
   if (n_packets == 0) return LCV_OK;
+  if (dmod && C / 8 <= 256 * GATE_MAXPK) {
+    const int64_t rows = B * T * S;
+    hipLaunchKernelGGL(gate_residual_bwd_dgate_kernel, dim3((unsigned)((rows + GATE_RPB - 1) / GATE_RPB)), dim3(256), 0,
+                       (hipStream_t)stream, (const bf16_t*)y, mod + gate_off, (const bf16_t*)dout, (bf16_t*)dy, dmod + gate_off,
+                       rows, (int)(C / 8), S, mod_stride);
+    LCV_LAUNCH_CHECK("gate_residual_bwd");
+    return LCV_OK;
+  }
   int64_t blocks = (n_packets + 255) / 256;
   if (blocks > 256 * 16) blocks = 256 * 16;
   hipLaunchKernelGGL(gate_residual_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
@@ -225,7 +320,9 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(
     const bf16_t* __restrict__ dk_out, bf16_t* __restrict__ dq_in, bf16_t* __restrict__ dk_in,
     const bf16_t* __restrict__ wq, const bf16_t* __restrict__ wk, const float* __restrict__ cs_tab, int H,
     int64_t in_sb, int64_t in_sn, int64_t q_sb, int64_t q_sn, int64_t kv_sb, int64_t kv_sn, int64_t din_sb,
-    int64_t din_sn, int64_t pos_off, float eps, float q_scale, float* __restrict__ dwq, float* __restrict__ dwk) {
+    int64_t din_sn, int64_t pos_off, float eps, float q_scale, float* __restrict__ dwq, float* __restrict__ dwk,
+    int dw_slots) {
+  __shared__ float s_dw[2][4][128];
   const int64_t n = blockIdx.x, b = blockIdx.y;
   const int sub = threadIdx.x & 15;
   const int hl = threadIdx.x >> 4;
@@ -253,17 +350,29 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_kernel(
       norm_rope_bwd_vec(k_in + b * in_sb + n * in_sn + off, dk_out + b * kv_sb + n * kv_sn + off,
                         dk_in + b * din_sb + n * din_sn + off, wkf, cs, do_rope, eps, 1.0f, dwk_acc, dwk != nullptr);
   }
-  // norm-weight gradients (only when asked for): sum over this wave's 4 heads-in-flight, then one atomic per (wave, dim)
+  // norm-weight gradients (only when asked for): sum over the wave's 4 heads-in-flight, then over the 4 waves through
+  // LDS, then ONE atomic per dim per workgroup into accumulator row (token % dw_slots) — every token of every layer
+  // call lands on the same 128 floats otherwise, and the kernel becomes a queue on those addresses
   if (dwq != nullptr || dwk != nullptr) {
+    const int wave = threadIdx.x >> 6;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       float a = dwq_acc[i], c = dwk_acc[i];
       a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
       c += __shfl_xor(c, 16, 64); c += __shfl_xor(c, 32, 64);
       if ((threadIdx.x & 63) < 16) {
-        if (dwq != nullptr && q_in) atomicAdd(dwq + sub * 8 + i, a);
-        if (dwk != nullptr && k_in) atomicAdd(dwk + sub * 8 + i, c);
+        s_dw[0][wave][sub * 8 + i] = a;
+        s_dw[1][wave][sub * 8 + i] = c;
       }
+    }
+    __syncthreads();
+    const int slot = (int)((n + b * gridDim.x) % dw_slots);
+    if (threadIdx.x < 128) {
+      const int d = threadIdx.x;
+      if (dwq != nullptr && q_in) atomicAdd(dwq + slot * 128 + d, s_dw[0][0][d] + s_dw[0][1][d] + s_dw[0][2][d] + s_dw[0][3][d]);
+    } else {
+      const int d = threadIdx.x - 128;
+      if (dwk != nullptr && k_in) atomicAdd(dwk + slot * 128 + d, s_dw[1][0][d] + s_dw[1][1][d] + s_dw[1][2][d] + s_dw[1][3][d]);
     }
   }
 }
@@ -272,16 +381,19 @@ extern "C" int lcv_qknorm_rope_bwd(const void* q_in, const void* k_in, const voi
                                    void* dq_in, void* dk_in, const void* wq, const void* wk, const void* cs,
                                    int64_t B, int64_t N, int64_t H, int64_t in_sb, int64_t in_sn, int64_t q_sb,
                                    int64_t q_sn, int64_t kv_sb, int64_t kv_sn, int64_t din_sb, int64_t din_sn,
-                                   int64_t pos_off, float eps, float q_scale, float* dwq, float* dwk, void* stream) {
+                                   int64_t pos_off, float eps, float q_scale, float* dwq, float* dwk, int64_t dw_slots,
+                                   void* stream) {
   LCV_CHECK_ARG((q_in || k_in) && wq && wk, "qknorm_rope_bwd: null pointer");
   LCV_CHECK_ARG(!q_in || (dq_out && dq_in), "qknorm_rope_bwd: q gradients missing");
   LCV_CHECK_ARG(!k_in || (dk_out && dk_in), "qknorm_rope_bwd: k gradients missing");
   LCV_CHECK_ARG(in_sn % 8 == 0 && q_sn % 8 == 0 && kv_sn % 8 == 0 && din_sn % 8 == 0, "qknorm_rope_bwd: strides % 8");
+  LCV_CHECK_ARG((!dwq && !dwk) || (dw_slots >= 1 && dw_slots <= 65536), "qknorm_rope_bwd: dw_slots");
   if (B == 0 || N == 0) return LCV_OK;
   hipLaunchKernelGGL(qknorm_rope_bwd_kernel, dim3((unsigned)N, (unsigned)B), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)q_in, (const bf16_t*)k_in, (const bf16_t*)dq_out, (const bf16_t*)dk_out,
                      (bf16_t*)dq_in, (bf16_t*)dk_in, (const bf16_t*)wq, (const bf16_t*)wk, (const float*)cs,
-                     (int)H, in_sb, in_sn, q_sb, q_sn, kv_sb, kv_sn, din_sb, din_sn, pos_off, eps, q_scale, dwq, dwk);
+                     (int)H, in_sb, in_sn, q_sb, q_sn, kv_sb, kv_sn, din_sb, din_sn, pos_off, eps, q_scale, dwq, dwk,
+                     (int)(dw_slots < 1 ? 1 : dw_slots));
   LCV_LAUNCH_CHECK("qknorm_rope_bwd");
   return LCV_OK;
 }

@@ -16,6 +16,9 @@
 #include <math.h>
 
 static constexpr int CHUNK = 2048;  // elements per workgroup (256 threads x 8)
+// per-tensor sum-of-squares accumulators: chunk c of a tensor adds into slot c % NORM_SLOTS of that tensor's row, the
+// coefficient kernel adds the row up.  One slot per tensor makes a 45 M-element weight (22 000 chunks) a queue on one address.
+static constexpr int NORM_SLOTS = 64;
 
 __device__ __forceinline__ int find_tensor(const lcv_adam_tensor* t, int n, int64_t chunk) {
   int lo = 0, hi = n - 1;
@@ -31,18 +34,29 @@ __global__ __launch_bounds__(256) void grad_sumsq_kernel(const lcv_adam_tensor* 
                                                          float* __restrict__ per_tensor) {
   const int ti = find_tensor(tensors, n, blockIdx.x);
   const lcv_adam_tensor t = tensors[ti];
-  const int64_t base = ((int64_t)blockIdx.x - t.first_chunk) * CHUNK + threadIdx.x * 8;
+  const int64_t chunk = (int64_t)blockIdx.x - t.first_chunk;
+  const int64_t base = chunk * CHUNK + threadIdx.x * 8;
   float acc = 0.f;
+  if (!F32 && base + 8 <= t.numel && (((uintptr_t)t.grad) & 15) == 0) {      // whole 16-byte packet
+    float g[8];
+    unpack8(*reinterpret_cast<const u16x8*>((const bf16_t*)t.grad + base), g);
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int64_t i = base + e;
-    if (i < t.numel) {
-      const float g = F32 ? ((const float*)t.grad)[i] : bf2f(((const bf16_t*)t.grad)[i]);
-      acc += g * g;
+    for (int e = 0; e < 8; ++e) acc = fmaf(g[e], g[e], acc);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int64_t i = base + e;
+      if (i < t.numel) {
+        const float g = F32 ? ((const float*)t.grad)[i] : bf2f(((const bf16_t*)t.grad)[i]);
+        acc += g * g;
+      }
     }
   }
+  __shared__ float part[4];
   acc = wave_sum(acc);
-  if ((threadIdx.x & 63) == 0) atomicAdd(per_tensor + ti, acc);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(per_tensor + (int64_t)ti * NORM_SLOTS + (chunk % NORM_SLOTS), part[0] + part[1] + part[2] + part[3]);
 }
 
 // total norm exactly as clip_grad_norm_ composes it: per-tensor norms (rounded to the grad dtype), then the
@@ -53,7 +67,9 @@ __global__ __launch_bounds__(256) void clip_coef_kernel(const float* __restrict_
   __shared__ float part[4];
   float acc = 0.f;
   for (int i = threadIdx.x; i < n; i += 256) {
-    float nrm = sqrtf(per_tensor[i]);
+    float sumsq = 0.f;
+    for (int k = 0; k < NORM_SLOTS; ++k) sumsq += per_tensor[(int64_t)i * NORM_SLOTS + k];
+    float nrm = sqrtf(sumsq);
     if (!F32) nrm = bfround(nrm);
     acc += nrm * nrm;
   }
@@ -122,7 +138,7 @@ extern "C" int lcv_grad_norm_clip(const lcv_adam_tensor* tensors, int64_t n_tens
                                   void* stream) {
   LCV_CHECK_ARG(tensors && per_tensor_ws && norm_coef_out && n_tensors > 0 && total_chunks > 0, "grad_norm_clip: bad arguments");
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(per_tensor_ws, 0, sizeof(float) * n_tensors, s) != hipSuccess) {
+  if (hipMemsetAsync(per_tensor_ws, 0, sizeof(float) * n_tensors * NORM_SLOTS, s) != hipSuccess) {
     lcv_set_error("grad_norm_clip: memset failed");
     return LCV_EDEVICE;
   }
@@ -176,6 +192,20 @@ __global__ __launch_bounds__(256) void sgd_kernel(const lcv_adam_tensor* __restr
   const lcv_adam_tensor t = tensors[ti];
   const int64_t base = ((int64_t)blockIdx.x - t.first_chunk) * CHUNK + threadIdx.x * 8;
   const float coef = clip ? clip[1] : 1.0f;
+  if (!F32 && base + 8 <= t.numel && ((((uintptr_t)t.param) | ((uintptr_t)t.grad)) & 15) == 0) {   // whole 16-byte packets
+    float p[8], g[8];
+    bf16_t* P = (bf16_t*)t.param + base;
+    unpack8(*reinterpret_cast<const u16x8*>(P), p);
+    unpack8(*reinterpret_cast<const u16x8*>((const bf16_t*)t.grad + base), g);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float gg = bfround(__fmul_rn(g[e], coef));
+      if (wd != 0.f) gg = bfround(__fadd_rn(gg, __fmul_rn(wd, p[e])));
+      p[e] = __fadd_rn(p[e], __fmul_rn(-lr, gg));
+    }
+    *reinterpret_cast<u16x8*>(P) = pack8(p);
+    return;
+  }
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int64_t i = base + e;

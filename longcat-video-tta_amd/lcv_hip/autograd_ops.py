@@ -94,7 +94,12 @@ class _LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             # a frozen base weight keeps a resident W^T (LoRA TTA); a trainable one changes every step, so its
             # transpose is a temporary
-            wt = w.detach().t().contiguous() if w.requires_grad else transposed_weight(w)
+            if not w.requires_grad:
+                wt = transposed_weight(w)
+            elif N % 64 == 0 and w.is_contiguous():
+                wt = ops.transpose_pad(w.detach())      # [K, N]: the HBM-bound transpose kernel, no padding needed
+            else:
+                wt = w.detach().t().contiguous()
             dx = ops.gemm_nt(dyb, wt, None)
         want_db = ctx.needs_input_grad[2]
         if w.requires_grad and N <= 32 and not want_db:          # adapter-sized: the skinny kernels

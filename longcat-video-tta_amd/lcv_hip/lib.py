@@ -22,7 +22,7 @@ _SIGNATURES = {
     "lcv_gate_residual_fwd": [P, P, P, P, I64, I64, I64, I64, I64, I64, P],
     "lcv_gate_residual_bwd": [P, P, P, P, P, I64, I64, I64, I64, I64, I64, P],
     "lcv_qknorm_rope_fwd": [P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, F32, F32, P],
-    "lcv_qknorm_rope_bwd": [P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, F32, F32, P, P, P],
+    "lcv_qknorm_rope_bwd": [P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, F32, F32, P, P, I64, P],
     "lcv_attn_fwd": [P, P, P, P, P, I64, I64, I64, I64] + [I64] * 12 + [F32, P],
     "lcv_attn_bwd": [P, P, P, P, P, P, P, P, P, P, I, I64, I64, I64, I64] + [I64] * 21 + [F32, P],
     "lcv_gemm_nt": [P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, I, I, P, P, I64, I64, I64, P],

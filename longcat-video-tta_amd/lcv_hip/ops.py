@@ -301,6 +301,9 @@ def gate_residual_bwd(y, mod, dout, gate_idx, T, need_dmod=False):
     return dy, dmod
 
 
+DW_SLOTS = 256
+
+
 def qknorm_rope_bwd(q_in, k_in, dq_out, dk_out, dq_in, dk_in, wq, wk, cs, pos_off=0, eps=1e-6, q_scale=1.0,
                     dwq: Optional[torch.Tensor] = None, dwk: Optional[torch.Tensor] = None):
     """dwq / dwk: optional fp32 [128] accumulators (zeroed by the caller) for the norm-weight gradients."""
@@ -312,9 +315,18 @@ def qknorm_rope_bwd(q_in, k_in, dq_out, dk_out, dq_in, dk_in, wq, wk, cs, pos_of
     for t in (q_in, k_in, dq_out, dk_out, dq_in, dk_in):
         if t is not None and (t.stride(3) != 1 or t.stride(2) != D):
             raise _lib.LcvError("qknorm_rope_bwd: (H, D) must be contiguous")
+    # the norm-weight gradients are accumulated into DW_SLOTS rows (token % DW_SLOTS) and added up afterwards: one 128-float
+    # target for every token of the call would serialise the kernel on those addresses
+    slots = DW_SLOTS if (dwq is not None or dwk is not None) else 1
+    sq = torch.zeros((slots, D), dtype=F32, device=ref.device) if dwq is not None else None
+    sk = torch.zeros((slots, D), dtype=F32, device=ref.device) if dwk is not None else None
     call("lcv_qknorm_rope_bwd", _ptr(q_in), _ptr(k_in), _ptr(dq_out), _ptr(dk_out), _ptr(dq_in), _ptr(dk_in),
          _ptr(wq), _ptr(wk), _ptr(cs), B, N, H, ref.stride(0), ref.stride(1), go.stride(0), go.stride(1),
-         gk.stride(0), gk.stride(1), gi.stride(0), gi.stride(1), pos_off, eps, q_scale, _ptr(dwq), _ptr(dwk), _stream())
+         gk.stride(0), gk.stride(1), gi.stride(0), gi.stride(1), pos_off, eps, q_scale, _ptr(sq), _ptr(sk), slots, _stream())
+    if dwq is not None:
+        dwq.add_(sq.sum(0))
+    if dwk is not None:
+        dwk.add_(sk.sum(0))
 
 
 def attention_bwd(q, k, v, o, do, lse, dq, dk, dv, scale, accumulate_kv=False):
@@ -378,6 +390,7 @@ class FusedAdamWClip:
     including the bf16 rounding points of the foreach implementation.  `param_groups` is kept so the reference's
     warm-up loop (`for pg in optimizer.param_groups: pg["lr"] = ...`) works unchanged."""
     CHUNK = 2048
+    NORM_SLOTS = 64   # partial sums of squares per tensor (csrc/optim.hip)
 
     def __init__(self, params, lr=2e-4, betas=(0.9, 0.999), weight_decay=0.01, eps=1e-8):
         self.params = [p for p in params]
@@ -392,7 +405,7 @@ class FusedAdamWClip:
         self.exp_avg_sq = [torch.zeros_like(p) for p in self.params]
         self.step_count = 0
         dev = self.params[0].device
-        self._ws = torch.zeros(len(self.params), dtype=F32, device=dev)
+        self._ws = torch.zeros(len(self.params) * self.NORM_SLOTS, dtype=F32, device=dev)
         self._norm_coef = torch.zeros(2, dtype=F32, device=dev)
         self._desc = None
         self._desc_key = None
@@ -445,7 +458,7 @@ class FusedAdamWClip:
         live = [o for o in opts if any(p.grad is not None for p in o.params)]
         for o in live:
             o.clip_grad_norm_(max_norm)                       # fills o._ws with the per-tensor sums of squares
-            sq = o._ws[:o._n_active].sqrt()
+            sq = o._ws[:o._n_active * o.NORM_SLOTS].view(o._n_active, o.NORM_SLOTS).sum(1).sqrt()
             if not o.f32:
                 sq = sq.to(BF16).to(F32)                      # a bf16 tensor's norm is a bf16 number
             total_sq += float((sq * sq).sum().item())
@@ -631,7 +644,7 @@ class FusedSGDClip(FusedAdamWClip):
         self.exp_avg_sq = self.params
         self.step_count = 0
         dev = self.params[0].device
-        self._ws = torch.zeros(len(self.params), dtype=F32, device=dev)
+        self._ws = torch.zeros(len(self.params) * self.NORM_SLOTS, dtype=F32, device=dev)
         self._norm_coef = torch.zeros(2, dtype=F32, device=dev)
         self._desc = None
         self._desc_key = None
