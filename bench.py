@@ -160,6 +160,17 @@ def measure_reference_point(dit, dev, pe, pm, ne, nm) -> dict:
     out["per_video_s"] = out["gen_s"] + out["tta20_s"]
     out["per_video_s_reference_h200"] = 167.6
     remove_lora_from_dit(dit)
+    # delta-A / AdaSteer-1 (one delta in R^512 on the timestep embedding; backward through all 48 frozen blocks down to t):
+    # 20 steps -> 82.8 s on 1x H200 (experimental_report.md:230-232)
+    from tta.delta import DeltaAWrapper, optimize_delta_a
+    wrap = DeltaAWrapper(dit, dit.config.adaln_tembed_dim).to(dev)
+    kw = dict(lr=1e-3, device=str(dev), dtype=torch.bfloat16)
+    optimize_delta_a(wrap, cond, train, pe, pm, num_steps=1, **kw)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    optimize_delta_a(wrap, cond, train, pe, pm, num_steps=20, **kw)
+    torch.cuda.synchronize(); out["delta_a20_s"] = time.perf_counter() - t0
+    out["delta_a20_s_reference_h200"] = 82.8
+    wrap.remove_from_dit()
     return out
 
 

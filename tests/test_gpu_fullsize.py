@@ -208,3 +208,51 @@ def test_fused_adamw_clip_full_lora_parameter_set_vs_torch():
             assert (d <= 2 * tol).all(), (step, tuple(p.shape), (d / tol).max().item())
             mism += (d != 0).sum().item(); tot += d.numel()
     assert mism / tot < 0.02, f"{mism}/{tot} elements differ from torch's AdamW"
+
+
+@pytest.mark.parametrize("M,N,K", [(25200, 3 * C, C), (6240, C, F_), (25200, 64, C)])
+def test_dense_weight_and_bias_gradients_full_size_vs_fp32(M, N, K):
+    """Full-model TTA's dense dW = dY^T X and db = colsum(dY) at the K3-TTA / reference-point token counts (25 200 and
+    6 240 tokens: neither a multiple of 64, so the zero padding of the transposed operands is exercised) against a plain
+    fp32 evaluation of a random subset of rows; transposes are checked exactly."""
+    ops = _ops()
+    g = torch.Generator(device=DEV).manual_seed(M + N)
+    x = torch.randn((M, K), generator=g, device=DEV).to(BF16)
+    dy = (torch.randn((M, N), generator=g, device=DEV) * 0.1).to(BF16)
+    dyT, xT = ops.transpose_pad(dy), ops.transpose_pad(x)
+    Mpad = (M + 63) // 64 * 64
+    assert dyT.shape == (N, Mpad) and xT.shape == (K, Mpad)
+    assert torch.equal(dyT[:, :M], dy.t()) and torch.equal(xT[:, :M], x.t())
+    assert not dyT[:, M:].any() and not xT[:, M:].any()
+    dw = ops.dense_wgrad(dyT, xT)
+    db = ops.rowsum(dyT)
+    assert dw.shape == (N, K) and dw.dtype == BF16
+    rows = torch.randperm(N, generator=torch.Generator().manual_seed(1))[:48].to(DEV)
+    ref = dy[:, rows].float().t() @ x.float()                       # [48, K] fp32
+    assert rel_l2(dw[rows], ref) < 3e-3, rel_l2(dw[rows], ref)
+    ref_b = dy.float().sum(0)
+    assert rel_l2(db, ref_b) < 3e-3
+    # linearity in dY: dW(2 dY) == 2 dW(dY) exactly (power-of-two scaling commutes with every rounding)
+    dw2 = ops.dense_wgrad(ops.transpose_pad((dy.float() * 2).to(BF16)), xT)
+    assert torch.equal(dw2.float(), dw.float() * 2)
+
+
+def test_fused_sgd_clip_on_a_13_6b_sized_tensor_list_property():
+    """The descriptor table / chunk arithmetic at full-model scale without 27 GB of state: 700 tensors of mixed sizes (one of
+    45 M elements like the fused w1|w3), gradient norm against torch, and an SGD step with coef == 1 and wd == 0 is exactly
+    p - lr * g rounded once."""
+    from lcv_hip.ops import FusedSGDClip
+    g = torch.Generator(device=DEV).manual_seed(3)
+    sizes = [45_088_768, 16_777_216, 4096, 128, 12288, 24576 * 512] + [4096 * 7 + 3] * 40
+    ps = [torch.nn.Parameter(torch.randn(n, generator=g, device=DEV).to(BF16)) for n in sizes]
+    for p in ps:
+        p.grad = (torch.randn(p.shape, generator=g, device=DEV) * 1e-4).to(BF16)
+    before = [p.detach().clone() for p in ps]
+    opt = FusedSGDClip(ps, lr=0.5, weight_decay=0.0)
+    n = opt.clip_grad_norm_(1e9)                                      # coefficient clamps to 1
+    ref = torch.sqrt(sum((p.grad.float().norm().to(BF16).float() ** 2) for p in ps))
+    assert abs(n.item() - ref.item()) <= 2 ** -7 * ref.item()
+    opt.step()
+    for p, b in zip(ps, before):
+        exp = (b.float() - 0.5 * p.grad.float()).to(BF16)
+        assert torch.equal(p.detach(), exp)
