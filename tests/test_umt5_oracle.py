@@ -57,3 +57,22 @@ def test_bucket_table_matches_transformers():
                         has_relative_attention_bias=True)
     d = torch.arange(-600, 601)
     assert torch.equal(O.relative_position_bucket(d), att._relative_position_bucket(d))
+
+
+def test_hip_encoder_loads_a_huggingface_checkpoint_unchanged(tmp_path):
+    """`UMT5EncoderModel.from_pretrained(ckpt, subfolder="text_encoder")` (common.py:62-64) on a directory written by
+    transformers' own `save_pretrained`: config keys, safetensors shards and parameter names must line up (loading only:
+    the forward needs the GPU)."""
+    from transformers import UMT5Config, UMT5EncoderModel as HF
+    from longcat_video.modules.umt5_encoder import UMT5EncoderModel
+    c = UMT5Config(vocab_size=320, d_model=128, d_kv=64, d_ff=192, num_layers=2, num_heads=2, feed_forward_proj="gated-gelu",
+                   dropout_rate=0.0)
+    hf = HF(c).eval().to(torch.bfloat16)
+    hf.save_pretrained(tmp_path / "text_encoder", safe_serialization=True)
+    m = UMT5EncoderModel.from_pretrained(str(tmp_path), subfolder="text_encoder", torch_dtype=torch.bfloat16)
+    assert (m.config.vocab_size, m.config.d_model, m.config.d_ff, m.config.num_layers, m.config.num_heads) == (320, 128, 192, 2, 2)
+    mine, theirs = m.state_dict(), hf.state_dict()
+    assert set(mine) == {k for k in theirs if k != "encoder.embed_tokens.weight"}
+    for k, v in mine.items():
+        assert torch.equal(v, theirs[k]), k
+    assert m.dtype == torch.bfloat16
