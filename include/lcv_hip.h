@@ -169,6 +169,12 @@ int lcv_gemm_nt(const void* a, const void* w, const void* bias,
                 const void* resid, const float* mod, int64_t rows_per_frame,
                 int64_t mod_stride, int64_t gate_off,
                 void* stream);
+/* Optional fp32 workspace (>= 16-byte aligned device memory, e.g. 64 MiB; NULL / 0 to withdraw) for the split-K tail of
+ * lcv_gemm_nt's persistent kernel: when the tile count leaves a last round with few busy CUs (784 tiles on 256 CUs at
+ * the reference's 480p operating point), those tail tiles are split along K into one partial round, summed and finished
+ * by a reduce kernel.  The library never allocates: without a workspace the tail runs unsplit.  One workspace per
+ * process, used by one stream at a time. */
+int lcv_gemm_set_workspace(void* ws, int64_t bytes);
 /* LoRA down-projection: h[M, Rpad] = bf16( s * bf16(x[M,K] @ A[R,K]^T) ), columns R..Rpad-1 zero.
  * (lora_down of LoRALinear, run_lora_tta.py:247-260). */
 int lcv_lora_down(const void* x, const void* A, void* h, int64_t M, int64_t K, int64_t R,

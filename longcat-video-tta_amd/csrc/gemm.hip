@@ -35,6 +35,11 @@ struct GemmParams {
   const float* gate;  // mod + gate_off
   int64_t rows_per_frame, mod_stride;
   int tiles_m, tiles_n, group_m;
+  // tile range of this launch (the persistent 8-phase kernel) and the split-K form of a tail launch: work item
+  // blockIdx.x = slice * vid_count + tile_local computes K tiles [slice * nk_split, +nk_split) of tile vid_begin + tile_local
+  // and leaves its fp32 accumulators in `ws` (register order); gemm8p_splitk_reduce_kernel adds the slices and runs the epilogue
+  int vid_begin, vid_count, splitk, nk_split;
+  float* ws;
   // implicit-GEMM convolution mode (channels-last activations [B,Tin,Hin,Win,Cin], rows m = output pixels):
   // K tiles run over (tap, 64-channel chunk); out-of-range taps read a zero page.
   int cv_T, cv_H, cv_W;        // output extent (rows m = ((b*T + t)*H + h)*W + w)
@@ -595,7 +600,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 // so a workgroup keeps its XCD's run of the sequence), and the LDS-DMA prologue of the NEXT tile is issued before the
 // epilogue of the current one - the 128 KiB LDS image allows one workgroup per CU, so without this every tile exposes
 // its own pipeline fill and its store tail.
-template <int EPI, bool PERSIST>
+template <int EPI, bool PERSIST, bool SPLIT = false>
 __global__ __launch_bounds__(512) void gemm8p_nt_kernel(const GemmParams p) {
   constexpr int BUF_BYTES = 65536, SLOT_BYTES = 16384;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -604,7 +609,13 @@ __global__ __launch_bounds__(512) void gemm8p_nt_kernel(const GemmParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
   const int r16 = lane & 15, q = lane >> 4;
-  const int nwg = p.tiles_m * p.tiles_n;
+  const int nwg = p.vid_begin + p.vid_count;   // end of this launch's tile range
+  int k_off = 0;                               // first K tile of this work item (split-K tail launches)
+  int nk = p.nk1 + p.nk2;                      // >= 2, nk1 >= 2 (host-checked)
+  if constexpr (SPLIT) {
+    k_off = (int)(blockIdx.x / (unsigned)p.vid_count) * p.nk_split;
+    nk = min(p.nk_split, nk - k_off);          // >= 2 (host-checked)
+  }
 #ifdef LCV_GEMM_STAMPS
   int gdbg_n = 0;
   unsigned long long* const gdbg_p = g_gdbg;
@@ -639,10 +650,11 @@ __global__ __launch_bounds__(512) void gemm8p_nt_kernel(const GemmParams p) {
       }
     }
   };
-  int vid = blockIdx.x;
+  int vid = p.vid_begin + (SPLIT ? (int)(blockIdx.x % (unsigned)p.vid_count) : (int)blockIdx.x);
   setup_tile(vid);
   auto stage_a = [&](auto mq_c, int kts, int buf) {
     constexpr int mq = decltype(mq_c)::value;
+    if constexpr (SPLIT) kts += k_off;
     const bool lora = kts >= p.nk1;  // the rank-r pair (a2, w2) supplies the last nk2 K tiles
     const char* base = lora ? (const char*)p.a2 + (int64_t)(kts - p.nk1) * 128 : (const char*)p.a + (int64_t)kts * 128;
     const unsigned ldb = (unsigned)(lora ? p.lda2 : p.lda) * 2u;
@@ -654,6 +666,7 @@ __global__ __launch_bounds__(512) void gemm8p_nt_kernel(const GemmParams p) {
   };
   auto stage_w = [&](auto nq_c, int kts, int buf) {
     constexpr int nq = decltype(nq_c)::value;
+    if constexpr (SPLIT) kts += k_off;
     const bool lora = kts >= p.nk1;
     const char* base = lora ? (const char*)p.w2 + (int64_t)(kts - p.nk1) * 128 : (const char*)p.w + (int64_t)kts * 128;
     const unsigned ldb = (unsigned)(lora ? p.ldw2 : p.ldw) * 2u;
@@ -751,7 +764,6 @@ __global__ __launch_bounds__(512) void gemm8p_nt_kernel(const GemmParams p) {
   };
 
   // ---- prologue: the steady-state issue order A-mq0, W-nq0, W-nq1, A-mq1 of tile 0, then A-mq0, W-nq0 of tile 1 ----
-  const int nk = p.nk1 + p.nk2;  // >= 2, nk1 >= 2 (host-checked)
   auto prologue = [&]() {
     stage_a(C0{}, 0, 0);
     stage_w(C0{}, 0, 0);
@@ -796,7 +808,15 @@ __global__ __launch_bounds__(512) void gemm8p_nt_kernel(const GemmParams p) {
     if (wr == 0) __builtin_amdgcn_s_barrier();  // balance the stagger
 
     const int64_t mw = m0 + wr * 128, nw = n0 + wc * 64;
-    if constexpr (PERSIST) {
+    if constexpr (SPLIT) {
+      // partial sums of this K slice, in register order: 32 coalesced 16-byte stores per lane
+      float* wsp = p.ws + ((int64_t)blockIdx.x * 32 * 512 + tid) * 4;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4v*>(wsp + (int64_t)(i * 4 + j) * 512 * 4) = acc[i][j];
+      break;
+    } else if constexpr (PERSIST) {
       // every wave is past its last LDS read: both buffers are free, so the next tile's pipeline fills under this epilogue
       const int next = vid + (int)gridDim.x;
       const bool more = next < nwg;
@@ -819,6 +839,65 @@ __global__ __launch_bounds__(512) void gemm8p_nt_kernel(const GemmParams p) {
   }
 }
 
+// Adds the K slices of the tail tiles (same thread -> accumulator mapping as gemm8p_nt_kernel) and runs the normal epilogue.
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm8p_splitk_reduce_kernel(const GemmParams p) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int r16 = lane & 15, q = lane >> 4;
+  int tm, tn;
+  gemm_tile_coords(p, p.vid_begin + (int)blockIdx.x, tm, tn);
+  f32x4v acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  for (int sl = 0; sl < p.splitk; ++sl) {
+    const float* wsp = p.ws + (((int64_t)sl * p.vid_count + blockIdx.x) * 32 * 512 + tid) * 4;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] += *reinterpret_cast<const f32x4v*>(wsp + (int64_t)(i * 4 + j) * 512 * 4);
+  }
+  gemm16_epilogue<8, 4, EPI>(p, acc, (int64_t)tm * 256 + wr * 128, (int64_t)tn * 256 + wc * 64, r16, q);
+}
+
+// caller-supplied fp32 workspace for the split-K tail (lcv_gemm_set_workspace); one per process, used on one stream at a time
+static float* g_gemm_ws = nullptr;
+static int64_t g_gemm_ws_bytes = 0;
+
+extern "C" int lcv_gemm_set_workspace(void* ws, int64_t bytes) {
+  LCV_CHECK_ARG((ws == nullptr) == (bytes == 0) && bytes >= 0 && ((uintptr_t)ws % 16) == 0, "gemm_set_workspace: bad arguments");
+  g_gemm_ws = (float*)ws;
+  g_gemm_ws_bytes = bytes;
+  return LCV_OK;
+}
+
+// Tail of a persistent launch: ntiles = r * 256 + t tiles on 256 CUs cost r + 1 tile-times although the last round keeps
+// only t CUs busy.  With a workspace a SMALL tail is split s ways along K into t*s work items (one partial round of ~1/s
+// tile-time), summed and finished by the reduce kernel.  Returns the chosen s (1 = leave the tail alone).
+// Cost model in tile-times, fitted to in-process A/B runs (scratch/bench_kernels.py gemm_tail): the two extra kernel
+// boundaries cost ~0.15, every work item moves 2 x 256 KiB of fp32 partials through HBM (~0.0013 each), a slice costs its K
+// tiles + 2 of pipeline fill.  Measured: t = 16 (784 tiles, the 480p generation shapes) +4 % / +6 %; t = 144 (400 tiles)
+// -23 % when split 5 ways - the partial sums of a fat tail cost more than its idle CUs, so only thin tails qualify.
+static int choose_tail_split(int t, int nk, int64_t ws_bytes) {
+  if (t <= 0 || t > 32) return 1;
+  const char* e = getenv("LCV_GEMM_SPLITK_TAIL");
+  if (e && e[0] == '0') return 1;
+  int best_s = 1;
+  double best = 1.0;
+  for (int s = 2; s <= 16; ++s) {
+    const int nks = (nk + s - 1) / s;
+    if (nks < 4 || nk - (s - 1) * nks < 2) break;        // slices of >= 4 K tiles (the pipeline needs 2 to fill), none empty
+    if ((int64_t)t * s * 512 * 128 * 4 > ws_bytes) break;
+    const double cost = (double)((t * s + 255) / 256) * (nks + 2) / (double)nk + 0.15 + 0.0013 * t * s;
+    if (cost < best - 0.1) { best = cost; best_s = s; }
+  }
+  return best_s;
+}
+
 template <int EPI, bool PERSIST>
 static int launch_gemm8p(GemmParams& p, hipStream_t s) {
   p.tiles_m = (int)((p.M + 255) / 256);
@@ -836,7 +915,33 @@ static int launch_gemm8p(GemmParams& p, hipStream_t s) {
     }
     attr_set = true;
   }
-  unsigned grid = (unsigned)(p.tiles_m * p.tiles_n);
+  const int ntiles = p.tiles_m * p.tiles_n;
+  p.vid_begin = 0; p.vid_count = ntiles; p.splitk = 1; p.nk_split = 0; p.ws = nullptr;
+  if (PERSIST && ntiles > 256 && g_gemm_ws != nullptr) {
+    const int t = ntiles % 256, nk = p.nk1 + p.nk2;
+    const int sk = choose_tail_split(t, nk, g_gemm_ws_bytes);
+    if (sk > 1) {
+      auto skern = gemm8p_nt_kernel<LCV_EPI_NONE, false, true>;
+      static bool sattr_set = false;
+      if (!sattr_set) {
+        if (hipFuncSetAttribute((const void*)skern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+          lcv_set_error("gemm_nt: cannot raise dynamic LDS to %zu", lds);
+          return LCV_EDEVICE;
+        }
+        sattr_set = true;
+      }
+      p.vid_count = ntiles - t;                           // full rounds: every CU busy to the end
+      hipLaunchKernelGGL(kern, dim3(256), dim3(512), lds, s, p);
+      LCV_LAUNCH_CHECK("gemm8p_nt");
+      p.vid_begin = ntiles - t; p.vid_count = t; p.splitk = sk; p.nk_split = (nk + sk - 1) / sk; p.ws = g_gemm_ws;
+      hipLaunchKernelGGL(skern, dim3((unsigned)(t * sk)), dim3(512), lds, s, p);
+      LCV_LAUNCH_CHECK("gemm8p_nt_splitk");
+      hipLaunchKernelGGL(gemm8p_splitk_reduce_kernel<EPI>, dim3((unsigned)t), dim3(512), 0, s, p);
+      LCV_LAUNCH_CHECK("gemm8p_splitk_reduce");
+      return LCV_OK;
+    }
+  }
+  unsigned grid = (unsigned)ntiles;
   if (PERSIST && grid > 256) grid = 256;  // one workgroup per CU (the LDS image allows no more); a multiple of 8 XCDs
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, p);
   LCV_LAUNCH_CHECK("gemm8p_nt");
@@ -924,7 +1029,7 @@ extern "C" int lcv_gemm_nt(const void* a, const void* w, const void* bias, const
                 "gemm_nt: operand row strides must be multiples of 8 elements (16 bytes)");
   LCV_CHECK_ARG(((uintptr_t)a % 16 == 0) && ((uintptr_t)w % 16 == 0), "gemm_nt: operands must be 16-byte aligned");
   if (M == 0) return LCV_OK;
-  GemmParams p;
+  GemmParams p{};
   p.a = (const bf16_t*)a; p.w = (const bf16_t*)w; p.bias = (const bf16_t*)bias;
   p.a2 = (const bf16_t*)a2; p.w2 = (const bf16_t*)w2; p.c = c;
   p.M = M; p.N = N; p.nk1 = (int)(K / 64); p.nk2 = (int)(K2 / 64);
@@ -962,7 +1067,7 @@ static int conv3d_impl(const void* x, const void* w, const void* bias, const voi
                        int64_t B, int64_t Tin, int64_t Hin, int64_t Win, int64_t Cin, int64_t Cout, int64_t ldc, int kt, int kh,
                        int kw, int up2x, int st, int sh, int sw, int pt, int ph, int pw, int64_t Tout, int64_t Hout,
                        int64_t Wout, void* stream) {
-  GemmParams p;
+  GemmParams p{};
   p.a = (const bf16_t*)x; p.w = (const bf16_t*)w; p.bias = (const bf16_t*)bias; p.a2 = nullptr; p.w2 = nullptr;
   p.c = out;
   p.cv_T = (int)Tout; p.cv_H = (int)Hout; p.cv_W = (int)Wout;

@@ -26,6 +26,7 @@ _SIGNATURES = {
     "lcv_attn_fwd": [P, P, P, P, P, I64, I64, I64, I64] + [I64] * 12 + [F32, P],
     "lcv_attn_bwd": [P, P, P, P, P, P, P, P, P, P, I, I64, I64, I64, I64] + [I64] * 21 + [F32, P],
     "lcv_gemm_nt": [P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, I, I, P, P, I64, I64, I64, P],
+    "lcv_gemm_set_workspace": [P, I64],
     "lcv_linear_f32_smallm": [P, P, P, P, I64, I64, I64, I, P],
     "lcv_lora_down": [P, P, P, I64, I64, I64, I64, I64, F32, P],
     "lcv_tn_skinny": [P, P, P, I64, I64, I64, I64, I64, F32, P],

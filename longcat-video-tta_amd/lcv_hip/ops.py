@@ -145,6 +145,21 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float,
 
 
 # ------------------------------------------------------------------ GEMMs ---
+_GEMM_WS = {}   # device index -> the split-K tail workspace handed to the library (kept alive here)
+GEMM_WS_BYTES = 256 << 20
+
+
+def _ensure_gemm_workspace(device: torch.device) -> None:
+    """Give liblcv_hip.so its split-K tail workspace once per process (one process per GPU): the library never allocates."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _GEMM_WS:
+        if _GEMM_WS:                       # a second device in the same process: the library holds ONE workspace
+            return
+        ws = torch.empty(GEMM_WS_BYTES, dtype=torch.uint8, device=device)
+        call("lcv_gemm_set_workspace", _ptr(ws), GEMM_WS_BYTES)
+        _GEMM_WS[idx] = ws
+
+
 def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *,
             a2: Optional[torch.Tensor] = None, w2: Optional[torch.Tensor] = None,
             epilogue: int = LCV_EPI_NONE, out_f32: bool = False, resid: Optional[torch.Tensor] = None,
@@ -152,6 +167,8 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = Non
             out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """c[M,N] = a[M,K] @ w[N,K]^T (+ a2 @ w2^T) + bias with a fused epilogue."""
     _req(a, BF16, "gemm_nt.a"); _req(w, BF16, "gemm_nt.w")
+    if a.shape[0] >= 2048:
+        _ensure_gemm_workspace(a.device)
     if a.dim() != 2 or w.dim() != 2 or a.stride(1) != 1 or w.stride(1) != 1:
         raise _lib.LcvError("gemm_nt: a and w must be 2-D with contiguous rows")
     M, K = a.shape

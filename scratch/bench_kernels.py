@@ -96,3 +96,18 @@ if which in ("eval",):
             print(f"eval {N}x{H}x{W} win {win}: sqerr {m1*1e3:.1f} us {by/m1/1e6:.0f} GB/s | ssim {m2*1e3:.1f} us {by/m2/1e6:.0f} GB/s", flush=True)
         full = lambda: ops.frame_metrics(gen, gt)
         print(f"  frame_metrics end to end (2 launches + partial sums + D2H): {timeit(full, n=10, warm=2)*1e3:.1f} us", flush=True)
+if which in ("gemm_tail",):
+    # the reference's 480p operating shapes (generation: M = 2 x 6 240 rows; TTA: M = 6 240): thin last rounds on 256 CUs,
+    # with and without the split-K tail, interleaved in one process
+    for (M,N,K,name) in ((12480,4096,4096,"proj@12480"),(12480,12288,4096,"qkv@12480"),(12480,4096,11008,"w2@12480"),
+                         (6240,4096,4096,"proj@6240"),(6240,12288,4096,"qkv@6240"),(6240,11008,4096,"w1@6240"),(6240,4096,11008,"w2@6240")):
+        a=torch.randn(M,K,device=dev,dtype=bf); w=torch.randn(N,K,device=dev,dtype=bf)*0.02; b=torch.randn(N,device=dev,dtype=bf)
+        res={}
+        for rep in range(3):
+            for split in ("0","1"):
+                os.environ["LCV_GEMM_SPLITK_TAIL"]=split
+                res.setdefault(split,[]).append(timeit(lambda: ops.gemm_nt(a,w,b), n=10, warm=2))
+        m0,m1=min(res["0"]),min(res["1"])
+        tiles=((M+255)//256)*((N+255)//256)
+        print(f"{name}: {tiles} tiles ({tiles/256:.2f} rounds)  unsplit {m0*1e3:.0f} us {2*M*N*K/m0/1e9:.0f} TF/s | split-K tail {m1*1e3:.0f} us {2*M*N*K/m1/1e9:.0f} TF/s  ({(m0/m1-1)*100:+.1f} %)", flush=True)
+        del a,w

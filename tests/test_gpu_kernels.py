@@ -233,6 +233,45 @@ def test_gemm_persistent_many_tiles_bitwise(monkeypatch):
         assert torch.equal(ops.gemm_nt(a, w, b), ref)
 
 
+@pytest.mark.parametrize("M,N,K,kind", [(12480, 4096, 4096, "plain"), (12480, 4096, 4096, "gate_residual"),
+                                        (12480, 4096, 4096, "lora"), (12480, 4096, 11008, "f32out"), (12480 - 300, 4096 + 40, 1024, "plain")])
+def test_gemm_splitk_tail_matches_unsplit_and_fp32(M, N, K, kind, monkeypatch):
+    """Tile counts that leave a thin last round on 256 CUs (784 = 3*256 + 16 tiles at the reference's 480p generation
+    shapes; 48 x 17 = 816 = 3*256 + 48... is too fat and stays unsplit): the tail tiles are split along K, summed in fp32 and
+    finished by the reduce kernel.
+    Same epilogues as the unsplit kernel; results equal the unsplit ones up to the order of the fp32 partial sums (a
+    handful of bf16 ulps on < 1 % of the elements) and the fp32 reference within the GEMM tolerance."""
+    ops = _ops()
+    from lcv_hip.lib import LCV_EPI_GATE_RESIDUAL
+    a = _randn(M, K, seed=81).to(DEV); w = _randn(N, K, seed=82, scale=0.03).to(DEV); b = _randn(N, seed=83).to(DEV)
+    kw = {}
+    if kind == "gate_residual":
+        T = 8
+        kw = dict(epilogue=LCV_EPI_GATE_RESIDUAL, resid=_randn(M, N, seed=84).to(DEV),
+                  mod=_randn(1, T, 3 * N, seed=85, dtype=torch.float32).to(DEV), gate_idx=2, rows_per_frame=M // T)
+    if kind == "lora":
+        kw = dict(a2=_randn(M, 64, seed=86).to(DEV), w2=_randn(N, 64, seed=87, scale=0.05).to(DEV))
+    if kind == "f32out":
+        kw = dict(out_f32=True)
+    monkeypatch.setenv("LCV_GEMM_SPLITK_TAIL", "0")
+    ref = ops.gemm_nt(a, w, b, **kw)
+    monkeypatch.delenv("LCV_GEMM_SPLITK_TAIL")
+    out = ops.gemm_nt(a, w, b, **kw)
+    assert torch.equal(ops.gemm_nt(a, w, b, **kw), out)            # deterministic (no atomics)
+    d = (out.float() - ref.float()).abs()
+    if kind != "f32out":                                            # bf16 outputs hide most of the fp32 reordering
+        assert (d > 0).float().mean() < 0.01, (d > 0).float().mean()
+    assert rel_l2(out, ref) < 2e-4, rel_l2(out, ref)
+    if N == 4096:
+        assert (d > 0).any()                                        # 784 tiles: the split path really ran
+    else:
+        assert not (d > 0).any()                                    # 48 x 17 = 816 tiles: tail of 48, left alone
+    if kind in ("plain", "f32out"):
+        rows = torch.randperm(M, generator=torch.Generator().manual_seed(2))[:64].to(DEV)
+        exact = a[rows].float() @ w.float().t() + b.float()
+        assert rel_l2(out[rows], exact) < 2e-3
+
+
 def test_linear_f32_smallm():
     ops, orc = _ops(), _orc()
     import torch.nn.functional as F
