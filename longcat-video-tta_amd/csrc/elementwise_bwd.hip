@@ -563,41 +563,76 @@ extern "C" int lcv_linear_f32_smallm_bwd(const float* dy, const void* w, const f
 // dA = (s dy B)^T x  and  dB^T = h^T dy  are both of this form.  HBM-bound on x (read once per 8 ranks);
 // each workgroup owns 2048 columns x 128 rows and publishes its partial with fp32 atomics (256-byte runs).
 // ---------------------------------------------------------------------------
+// Layout: a workgroup owns 512 columns (4 waves x the SAME 64 lanes x 8 columns) and `rpb` rows; its 4 waves each take a
+// quarter of those rows, their partial sums meet in LDS and ONE wave publishes them.  The fp32 atomics are the cross-
+// workgroup part of the reduction and were the bound of the first version (one set per 128 rows: 6.4 M atomics per call at
+// 25 200 tokens, ~1 TB/s); with ~32 row groups per call they are 1 M and the kernel streams x.
+#define TN_MAXROWS 1024
 template <int RC>
 __global__ __launch_bounds__(256) void tn_skinny_kernel(const bf16_t* __restrict__ g, const bf16_t* __restrict__ x,
                                                         float* __restrict__ out, int64_t M, int64_t K, int R,
-                                                        int Rpad, int64_t ldx, int r0, float scale) {
-  constexpr int ROWS = 128;
-  __shared__ float sg[ROWS][RC];
-  const int64_t m0 = (int64_t)blockIdx.y * ROWS;
-  const int64_t k = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
-  const int nrows = (int)((M - m0) < ROWS ? (M - m0) : ROWS);
-  for (int i = threadIdx.x; i < ROWS * RC; i += 256) {
+                                                        int Rpad, int64_t ldx, int r0, float scale, int rpb) {
+  __shared__ float smem[3 * 64 * RC * 8];                 // 48 KB: first the g rows [rpb][RC], then 3 waves' partials
+  static_assert(3 * 64 * RC * 8 >= TN_MAXROWS * RC, "LDS image too small for the g rows");
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t m0 = (int64_t)blockIdx.y * rpb;
+  const int64_t k = ((int64_t)blockIdx.x * 64 + lane) * 8;
+  const int nrows = (int)((M - m0) < rpb ? (M - m0) : rpb);
+  for (int i = threadIdx.x; i < rpb * RC; i += 256) {
     const int m = i / RC, rr = i - m * RC;
-    sg[m][rr] = (m < nrows && r0 + rr < R) ? bf2f(g[(m0 + m) * Rpad + r0 + rr]) : 0.f;
+    smem[i] = (m < nrows && r0 + rr < R) ? bf2f(g[(m0 + m) * Rpad + r0 + rr]) : 0.f;
   }
   __syncthreads();
-  if (k >= K) return;
   float acc[RC][8];
 #pragma unroll
   for (int rr = 0; rr < RC; ++rr)
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[rr][e] = 0.f;
-  for (int m = 0; m < nrows; ++m) {
-    float xf[8];
-    unpack8(*reinterpret_cast<const u16x8*>(x + (m0 + m) * ldx + k), xf);
+  const int q = (rpb + 3) / 4;                            // rows per wave (rpb % 4 == 0)
+  const int mb = wave * q, me = min(mb + q, nrows);
+  if (k < K) {
+    for (int m = mb; m < me; m += 8) {
+      u16x8 raw[8];
 #pragma unroll
-    for (int rr = 0; rr < RC; ++rr) {
-      const float gv = sg[m][rr];
+      for (int u = 0; u < 8; ++u) {
+        const int mm = m + u < me ? m + u : me - 1;       // clamped address; its weight is zeroed below
+        raw[u] = *reinterpret_cast<const u16x8*>(x + (m0 + mm) * ldx + k);
+      }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[rr][e] += gv * xf[e];
+      for (int u = 0; u < 8; ++u) {
+        float xf[8];
+        unpack8(raw[u], xf);
+        const bool live = m + u < me;
+#pragma unroll
+        for (int rr = 0; rr < RC; ++rr) {
+          const float gv = live ? smem[(m + u) * RC + rr] : 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[rr][e] += gv * xf[e];
+        }
+      }
     }
   }
+  __syncthreads();                                         // every wave is done with the g rows
+  if (wave > 0) {
+    float* dst = smem + ((wave - 1) * 64 + lane) * RC * 8;
 #pragma unroll
-  for (int rr = 0; rr < RC; ++rr) {
-    if (r0 + rr < R) {
+    for (int rr = 0; rr < RC; ++rr)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) atomicAdd(out + (int64_t)(r0 + rr) * K + k + e, acc[rr][e] * scale);
+      for (int e = 0; e < 8; ++e) dst[rr * 8 + e] = acc[rr][e];
+  }
+  __syncthreads();
+  if (wave == 0 && k < K) {
+#pragma unroll
+    for (int rr = 0; rr < RC; ++rr) {
+      if (r0 + rr < R) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float v = acc[rr][e];
+#pragma unroll
+          for (int w2 = 0; w2 < 3; ++w2) v += smem[(w2 * 64 + lane) * RC * 8 + rr * 8 + e];
+          atomicAdd(out + (int64_t)(r0 + rr) * K + k + e, v * scale);
+        }
+      }
     }
   }
 }
@@ -607,10 +642,13 @@ extern "C" int lcv_tn_skinny(const void* g, const void* x, float* out, int64_t M
   LCV_CHECK_ARG(g && x && out, "tn_skinny: null pointer");
   LCV_CHECK_ARG(K % 8 == 0 && ldx % 8 == 0 && R >= 1 && R <= Rpad, "tn_skinny: bad shape");
   if (M == 0) return LCV_OK;
-  const dim3 grid((unsigned)((K + 2047) / 2048), (unsigned)((M + 127) / 128));
+  int64_t rpb = ((M + 31) / 32 + 3) / 4 * 4;              // ~32 row groups per call
+  if (rpb > TN_MAXROWS) rpb = TN_MAXROWS;
+  if (rpb < 64) rpb = 64;
+  const dim3 grid((unsigned)((K + 511) / 512), (unsigned)((M + rpb - 1) / rpb));
   for (int r0 = 0; r0 < R; r0 += 8) {
     hipLaunchKernelGGL(tn_skinny_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)g,
-                       (const bf16_t*)x, out, M, K, (int)R, (int)Rpad, ldx, r0, scale);
+                       (const bf16_t*)x, out, M, K, (int)R, (int)Rpad, ldx, r0, scale, (int)rpb);
     LCV_LAUNCH_CHECK("tn_skinny");
   }
   return LCV_OK;

@@ -111,3 +111,9 @@ if which in ("gemm_tail",):
         tiles=((M+255)//256)*((N+255)//256)
         print(f"{name}: {tiles} tiles ({tiles/256:.2f} rounds)  unsplit {m0*1e3:.0f} us {2*M*N*K/m0/1e9:.0f} TF/s | split-K tail {m1*1e3:.0f} us {2*M*N*K/m1/1e9:.0f} TF/s  ({(m0/m1-1)*100:+.1f} %)", flush=True)
         del a,w
+if which in ("skinny",):
+    # LoRA parameter-gradient contraction (dA: x [M, 4096]; dB: dy [M, 12288]) at the K3-TTA token count; HBM-bound on x
+    for (M, K) in ((25200, 4096), (25200, 12288), (6240, 4096)):
+        x = torch.randn(M, K, device=dev, dtype=bf); g = torch.randn(M, 64, device=dev, dtype=bf)
+        ms = timeit(lambda: ops.tn_skinny(g, x, 8), n=20, warm=3)
+        print(f"tn_skinny M={M} K={K} R=8: {ms*1e3:.0f} us  {M*K*2/ms/1e6:.0f} GB/s", flush=True)
