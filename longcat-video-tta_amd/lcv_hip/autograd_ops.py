@@ -6,7 +6,7 @@ loop).  Frozen base weights never get a gradient (LoRA-only backward): `dx = dy 
 resident transposed copy of W so that forward and backward share the one NT GEMM kernel.
 """
 import weakref
-from typing import List, Optional, Tuple
+from typing import List, Optional
 
 import torch
 

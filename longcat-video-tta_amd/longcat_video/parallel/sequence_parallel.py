@@ -8,7 +8,7 @@ Collectives (torch.distributed; backend "nccl" = RCCL over xGMI on MI355X, "gloo
 xGMI is point-to-point (7 links per GPU): RCCL's all-gather on a fully connected 8-GPU node is issued as direct peer
 exchanges, so a per-layer message of 2*N*C*2 bytes (792 MB at K5) moves over all 7 links, not around a ring.
 """
-from typing import List, Optional, Tuple
+from typing import List, Tuple
 
 import torch
 

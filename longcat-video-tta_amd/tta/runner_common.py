@@ -7,7 +7,7 @@ import json
 import os
 import time
 from pathlib import Path
-from typing import Callable, Dict, List
+from typing import Callable, Dict
 
 import numpy as np
 import torch

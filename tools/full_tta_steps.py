@@ -4,7 +4,6 @@ width and depth: `python tools/full_tta_steps.py [depth=48] [480p|720p] [sgd|ada
 (6 240 tokens, the reference's operating point); 720p: Tc=4 + Tt=3 (25 200 tokens)."""
 import functools
 import sys
-import time
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[1]
