@@ -196,7 +196,7 @@ def measure_full_tta_reference_point(dit, dev, pe, pm) -> dict:
     for p_ in dit.parameters():
         p_.requires_grad = True
     kw = dict(lr=1e-5, warmup_steps=2, device=str(dev), dtype=torch.bfloat16, optimizer_type="sgd")
-    finetune_full_on_conditioning(dit, cond, train, pe, pm, num_steps=1, **kw)
+    finetune_full_on_conditioning(dit, cond, train, pe, pm, num_steps=2, **kw)   # warm-up: allocator sizes, weight-transpose buffers
     torch.cuda.synchronize(); t0 = time.perf_counter()
     res = finetune_full_on_conditioning(dit, cond, train, pe, pm, num_steps=5, **kw)
     torch.cuda.synchronize()
