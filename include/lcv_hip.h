@@ -117,6 +117,11 @@ int lcv_qknorm_rope_bwd(const void* q_in, const void* k_in,
                         int64_t din_sb, int64_t din_sn,
                         int64_t pos_off, float eps, float q_scale, float* dwq, float* dwk, int64_t dw_slots, void* stream);
 
+/* Sinusoidal timestep features, fp32: out[i, :dim/2] = cos(t_i f), out[i, dim/2:] = sin(t_i f), f_j = max_period^(-j/(dim/2)).
+ * Input of the DiT's timestep MLP (upstream TimestepEmbedder.timestep_embedding; outer forward restated at
+ * delta_experiment/scripts/run_delta_a.py:160-166). */
+int lcv_timestep_embedding(const float* t, float* out, int64_t n, int64_t dim, float max_period, void* stream);
+
 /* ---- flash attention (dense, non-causal, head_dim 128, bf16, fp32 acc) */
 /* o[b,n,h,:] = softmax(q k^T * scale) v ; q: Nq rows, k/v: Nk rows.
  * Every tensor is addressed ptr + b*s_b + n*s_n + h*s_h + d with d contiguous.

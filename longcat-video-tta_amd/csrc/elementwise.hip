@@ -530,3 +530,27 @@ extern "C" int lcv_fm_mse(const float* pred, const void* eps, const void* x0, fl
   LCV_LAUNCH_CHECK("fm_mse");
   return LCV_OK;
 }
+
+// ---------------------------------------------------------------------------
+// Sinusoidal timestep features (the input of the timestep MLP): out[i, j] = cos(t_i f_j) for j < half, sin(t_i f_j) after,
+// f_j = exp(-ln(max_period) j / half), all fp32 — the one piece of arithmetic the DiT forward still did in torch.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void timestep_embedding_kernel(const float* __restrict__ t, float* __restrict__ out, int n,
+                                                                 int half, float neg_log_period_over_half) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n * half) return;
+  const int i = idx / half, j = idx - i * half;
+  const float arg = t[i] * expf(neg_log_period_over_half * (float)j);
+  out[(int64_t)i * 2 * half + j] = cosf(arg);
+  out[(int64_t)i * 2 * half + half + j] = sinf(arg);
+}
+
+extern "C" int lcv_timestep_embedding(const float* t, float* out, int64_t n, int64_t dim, float max_period, void* stream) {
+  LCV_CHECK_ARG(t && out && n >= 0 && dim > 0 && dim % 2 == 0 && max_period > 1.f, "timestep_embedding: bad arguments");
+  if (n == 0) return LCV_OK;
+  const int half = (int)(dim / 2);
+  hipLaunchKernelGGL(timestep_embedding_kernel, dim3((unsigned)((n * half + 255) / 256)), dim3(256), 0, (hipStream_t)stream, t, out,
+                     (int)n, half, -logf(max_period) / (float)half);
+  LCV_LAUNCH_CHECK("timestep_embedding");
+  return LCV_OK;
+}

@@ -31,6 +31,7 @@ _SIGNATURES = {
     "lcv_lora_down": [P, P, P, I64, I64, I64, I64, I64, F32, P],
     "lcv_tn_skinny": [P, P, P, I64, I64, I64, I64, I64, F32, P],
     "lcv_linear_f32_smallm_bwd": [P, P, P, P, I64, I64, I64, I, P],
+    "lcv_timestep_embedding": [P, P, I64, I64, F32, P],
     "lcv_swiglu_fwd": [P, P, P, I64, I64, I64, P],
     "lcv_swiglu_bwd": [P, P, P, P, P, I64, I64, I64, P],
     "lcv_patchify": [P, P, I64, I64, I64, I64, I64, I64, P],

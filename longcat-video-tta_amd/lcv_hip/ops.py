@@ -70,6 +70,15 @@ def gate_residual(x: torch.Tensor, y: torch.Tensor, mod: Optional[torch.Tensor],
     return out
 
 
+def timestep_embedding(t: torch.Tensor, dim: int, max_period: float = 10000.0) -> torch.Tensor:
+    """t fp32 [n] -> [n, dim] fp32 (cos | sin)."""
+    _req(t, F32, "timestep_embedding.t")
+    t = t.contiguous().view(-1)
+    out = torch.empty((t.numel(), dim), dtype=F32, device=t.device)
+    call("lcv_timestep_embedding", _ptr(t), _ptr(out), t.numel(), dim, float(max_period), _stream())
+    return out
+
+
 # ------------------------------------------------------- q/k norm + rope ---
 def qknorm_rope(q_in: Optional[torch.Tensor], k_in: Optional[torch.Tensor], v_in: Optional[torch.Tensor],
                 q_out: Optional[torch.Tensor], k_out: Optional[torch.Tensor], v_out: Optional[torch.Tensor],

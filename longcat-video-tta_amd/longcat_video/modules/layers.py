@@ -6,7 +6,6 @@ linears are real `nn.Linear` subclasses invoked through `__call__`, so the refer
 patching (:137-140) and forward hooks (delta_experiment/scripts/run_film_tta.py:146-163) all take
 effect; fused fast paths are used only while the modules they swallow are pristine.
 """
-import math
 from typing import Optional, Tuple
 
 import torch
@@ -293,10 +292,7 @@ class TimestepEmbedder(nn.Module):
 
     @staticmethod
     def timestep_embedding(t, dim, max_period=10000):
-        half = dim // 2
-        freqs = torch.exp(-math.log(max_period) * torch.arange(half, dtype=torch.float32, device=t.device) / half)
-        args = t[:, None].float() * freqs[None]
-        return torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+        return ops.timestep_embedding(t.float(), dim, float(max_period))
 
     def forward(self, t, dtype=torch.float32):
         t_freq = self.timestep_embedding(t, self.frequency_embedding_size)

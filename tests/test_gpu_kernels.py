@@ -272,6 +272,17 @@ def test_gemm_splitk_tail_matches_unsplit_and_fp32(M, N, K, kind, monkeypatch):
         assert rel_l2(out[rows], exact) < 2e-3
 
 
+def test_timestep_embedding_matches_oracle():
+    """Sinusoidal timestep features (fp32) against the oracle's torch evaluation: arguments reach 1000 rad, so the absolute
+    error of cos / sin is that of the fp32 product t * f (half an ulp of 1000 = 3e-5) on both sides."""
+    ops, orc = _ops(), _orc()
+    t = torch.tensor([0.0, 1.0, 37.5, 431.0, 612.0, 999.0, 1000.0], dtype=torch.float32)
+    got = ops.timestep_embedding(t.to(DEV), 256).cpu()
+    ref = orc.timestep_embedding(t, 256)
+    assert got.shape == (7, 256) and (got - ref).abs().max() < 2e-4
+    assert torch.equal(got[0], ref[0])                         # t = 0: cos 1, sin 0 exactly
+
+
 def test_linear_f32_smallm():
     ops, orc = _ops(), _orc()
     import torch.nn.functional as F
