@@ -23,10 +23,18 @@ from lcv_hip import ops
 RESOLUTIONS = {"480p": (480, 832), "720p": (720, 1280)}
 
 
-def retrieve_latents(encoder_output, generator=None, sample_mode: str = "argmax"):
+def retrieve_latents(encoder_output, generator=None, sample_mode: str = "sample"):
+    """diffusers' helper of the same name, which upstream's pipeline module copies ([assumed-from-upstream]: default
+    `sample_mode="sample"`, the signature every diffusers pipeline carries).  The reference calls it with the defaults
+    (`common.py:169-170`), i.e. it draws mean + std * eps from the posterior with the global RNG; the pipeline's own
+    conditioning encode asks for the mode explicitly, as the WAN image-to-video pipelines do."""
     if hasattr(encoder_output, "latent_dist"):
         d = encoder_output.latent_dist
-        return d.mode() if sample_mode == "argmax" else d.sample(generator)
+        if sample_mode == "sample":
+            return d.sample(generator)
+        if sample_mode == "argmax":
+            return d.mode()
+        raise AttributeError(f"unknown sample_mode {sample_mode!r}")
     if hasattr(encoder_output, "latents"):
         return encoder_output.latents
     if hasattr(encoder_output, "mode"):
@@ -186,7 +194,7 @@ class LongCatVideoPipeline:
         pe, pm, ne, nm = self._prep_text(prompt, negative_prompt, prompt_embeds, prompt_mask, negative_embeds,
                                          negative_mask, do_cfg)
         frames = self._frames_to_tensor(video, H, W)[:, :, -num_cond_frames:]
-        cond = retrieve_latents(self.vae.encode(frames.to(self.vae.dtype)))
+        cond = retrieve_latents(self.vae.encode(frames.to(self.vae.dtype)), sample_mode="argmax")
         mean = torch.tensor(self.vae.config.latents_mean, device=cond.device, dtype=torch.float32).view(1, -1, 1, 1, 1)
         std = torch.tensor(self.vae.config.latents_std, device=cond.device, dtype=torch.float32).view(1, -1, 1, 1, 1)
         cond = (cond.float() - mean) / std
