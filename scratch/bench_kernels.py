@@ -117,3 +117,23 @@ if which in ("skinny",):
         x = torch.randn(M, K, device=dev, dtype=bf); g = torch.randn(M, 64, device=dev, dtype=bf)
         ms = timeit(lambda: ops.tn_skinny(g, x, 8), n=20, warm=3)
         print(f"tn_skinny M={M} K={K} R=8: {ms*1e3:.0f} us  {M*K*2/ms/1e6:.0f} GB/s", flush=True)
+if which in ("attn_skipmax",):
+    # unit-score attention with (VAR 7) and without (VAR 3) the every-second-tile max skip, interleaved in one process;
+    # inputs shaped like the DiT's: q, k RMS-normalised rows (|row| = sqrt(128)), q pre-scaled into log2 units
+    import math
+    N=46800; H=32; D=128
+    g=torch.Generator(device=dev).manual_seed(0)
+    def rmsn(t): return t*torch.rsqrt(t.float().pow(2).mean(-1,keepdim=True)+1e-6)
+    q=rmsn(torch.randn(1,N,H,D,device=dev,generator=g)); k=rmsn(torch.randn(1,N,H,D,device=dev,generator=g)).to(bf)
+    v=torch.randn(1,N,H,D,device=dev,generator=g).to(bf)
+    q_pre=(q*(D**-0.5*math.log2(math.e))).to(bf)
+    o3=torch.empty(1,N,H,D,device=dev,dtype=bf); o7=torch.empty_like(o3)
+    fl=4*N*N*H*D
+    res={"3":[],"7":[]}
+    for rep in range(3):
+        for var,o in (("3",o3),("7",o7)):
+            os.environ["LCV_ATTN_VAR"]=var
+            res[var].append(timeit(lambda: ops.attention(q_pre,k,v,math.log(2.0),out=o), n=3, warm=1))
+    for var in ("3","7"):
+        print(f"attn unit VAR={var}: {min(res[var]):.2f} ms  {fl/min(res[var])/1e9:.1f} TF/s   all: {[round(x,2) for x in res[var]]}", flush=True)
+    d=(o3.float()-o7.float()); print("rel_l2 skipmax vs plain:", (d.norm()/o3.float().norm()).item(), "max abs", d.abs().max().item(), "finite", bool(torch.isfinite(o7.float()).all()))
