@@ -98,3 +98,46 @@ def compute_flow_matching_loss_conditioned_fixed(dit, cond_latents, target_laten
                 total += fm_mse_loss(pred, noise, target_latents, T_cond).item()
             count += 1
     return total / max(count, 1)
+
+
+# ---- the unconditioned variants (common.py:274-343, 346-407).  Every reference runner imports them and none calls them
+# (SURVEY §8 row a3); they are kept for API parity on the same two kernels (lcv_fm_noise, lcv_fm_mse with T_cond = 0).
+def compute_flow_matching_loss(dit, latents, prompt_embeds, prompt_mask, num_train_timesteps: int = 1000,
+                               sigma_min: float = 0.001, sigma_max: float = 1.0, device: str = "cuda",
+                               dtype: torch.dtype = torch.bfloat16, forward_fn=None) -> torch.Tensor:
+    cfg = _get_model_config(dit)
+    B, T_lat = latents.shape[0], latents.shape[2]
+    sigma = torch.rand(B, device=device, dtype=torch.float32) * (sigma_max - sigma_min) + sigma_min
+    noise = torch.randn_like(latents)
+    noisy = ops.fm_noise(latents.to(torch.bfloat16), noise.to(torch.bfloat16), sigma.to(torch.float32).expand(B).contiguous()).to(dtype)
+    timestep = (sigma * num_train_timesteps).unsqueeze(1).expand(B, T_lat // cfg.patch_size[0]).to(dtype)
+    if forward_fn is not None:
+        pred = forward_fn(noisy, timestep)
+    else:
+        pred = dit(hidden_states=noisy, timestep=timestep, encoder_hidden_states=prompt_embeds, encoder_attention_mask=prompt_mask)
+    return fm_mse_loss(pred, noise, latents, 0)
+
+
+def compute_flow_matching_loss_fixed(dit, latents, prompt_embeds, prompt_mask, fixed_sigmas: List[float], noise_draws: int = 1,
+                                     num_train_timesteps: int = 1000, device: str = "cuda",
+                                     dtype: torch.dtype = torch.bfloat16, forward_fn=None) -> float:
+    cfg = _get_model_config(dit)
+    B, T_lat = latents.shape[0], latents.shape[2]
+    total, count = 0.0, 0
+    for sigma_val in fixed_sigmas:
+        sigma = torch.tensor([sigma_val], device=device, dtype=torch.float32)
+        timestep = (sigma * num_train_timesteps).unsqueeze(1).expand(B, T_lat // cfg.patch_size[0]).to(dtype)
+        for draw_idx in range(noise_draws):
+            gen = torch.Generator(device=device)
+            gen.manual_seed(42 + draw_idx)                       # the reference's fixed seeds (:385-386)
+            noise = torch.randn(latents.shape, generator=gen, device=device, dtype=latents.dtype)
+            noisy = ops.fm_noise(latents.to(torch.bfloat16), noise.to(torch.bfloat16), sigma.expand(B).contiguous()).to(dtype)
+            with torch.no_grad():
+                if forward_fn is not None:
+                    pred = forward_fn(noisy, timestep)
+                else:
+                    pred = dit(hidden_states=noisy, timestep=timestep, encoder_hidden_states=prompt_embeds,
+                               encoder_attention_mask=prompt_mask)
+                total += fm_mse_loss(pred, noise, latents, 0).item()
+            count += 1
+    return total / max(count, 1)

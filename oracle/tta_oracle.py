@@ -117,6 +117,22 @@ def build_conditioned_inputs(cond, target, sigma, eps, patch_t: int = 1, num_tra
     return hidden, ts, N_cond
 
 
+# ---- common.py:274-343 / 346-407: the unconditioned variants (same sigma on every frame, no clean prefix; the fixed form
+# draws its noise from torch.Generator(device).manual_seed(42 + draw) in the LATENTS' dtype)
+def build_unconditioned_inputs(latents, sigma, eps, patch_t: int = 1, num_train_timesteps: int = 1000, dtype=BF16):
+    B, T = latents.shape[0], latents.shape[2]
+    se = sigma.view(-1, 1, 1, 1, 1)
+    noisy = ((1.0 - se) * latents + se * eps).to(dtype)
+    ts = (sigma * num_train_timesteps).unsqueeze(1).expand(B, T // patch_t).to(dtype)
+    return noisy, ts
+
+
+def unconditioned_fixed_noise(latents, draw_idx: int) -> torch.Tensor:
+    gen = torch.Generator(device=latents.device)
+    gen.manual_seed(42 + draw_idx)
+    return torch.randn(latents.shape, generator=gen, device=latents.device, dtype=latents.dtype)
+
+
 def conditioned_loss(pred, eps, target, T_cond: int) -> torch.Tensor:
     return F.mse_loss(pred[:, :, T_cond:].to(torch.float32), (eps - target).to(torch.float32))
 

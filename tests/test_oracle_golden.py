@@ -147,3 +147,23 @@ def test_adamw_clip_trace_bit_exact():
             g = O.r16(grads[i] * coef)
             ps[i], ms[i], vs[i] = O.adamw_step_bf16(ps[i], g, ms[i], vs[i], step + 1, lr_cur)
             assert torch.equal(ps[i].to(BF16), tr["after"][step][i]), (step, i)
+
+
+def test_unconditioned_loss_inputs_bit_exact():
+    """the unconditioned losses (common.py:274-407; imported by every runner, called by none) — what the
+    reference's functions handed to the toy DiT, restated by the oracle bit for bit."""
+    from oracle import tta_oracle as O
+    U = torch.load(G / "uncond_loss.pt")
+    t = U["uncond"]
+    sigma = t["sig_u"] * (1.0 - 0.001) + 0.001
+    hs, ts = O.build_unconditioned_inputs(t["latents"], sigma, t["eps"])
+    assert torch.equal(hs, t["hidden_states"]) and torch.equal(ts, t["timestep"]) and t["num_cond_latents"] == 0
+    f = U["uncond_fixed"]
+    k = 0
+    for s in f["sigmas"]:
+        for d in range(f["noise_draws"]):
+            eps = O.unconditioned_fixed_noise(f["latents"], d)
+            hs, ts = O.build_unconditioned_inputs(f["latents"], torch.tensor([s]), eps)
+            assert torch.equal(hs, f["hidden_states"][k]) and torch.equal(ts, f["timesteps"][k]), (s, d)
+            k += 1
+    assert k == f["hidden_states"].shape[0] == 4
