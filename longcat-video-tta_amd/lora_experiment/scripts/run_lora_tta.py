@@ -39,6 +39,8 @@ from tta.inner_loop import choose_gradient_checkpointing, finetune_lora_on_condi
 from tta.latent_split import _estimate_latent_len, num_frames_valid, split_tta_latents  # noqa: E402
 from tta.runner_common import (list_eval_entries, load_components, load_entry, save_frames,  # noqa: E402,F401
                                score_generation)
+from tta.lora import (count_builtin_lora_parameters, get_builtin_lora_parameters, inject_builtin_lora_into_dit,  # noqa: E402
+                      reset_builtin_lora_weights, save_builtin_lora_weights)
 from tta.lora import (count_lora_parameters, get_lora_parameters, inject_lora_into_dit, reset_lora_weights,  # noqa: E402
                       save_lora_weights)
 
@@ -92,9 +94,6 @@ def main(argv=None):
     C.normalize_tta_frame_args(args)
     C.validate_tta_feature_budget(args, context="lora_tta")
     C.reject_out_of_scope(args)
-    if args.use_builtin_lora:
-        raise NotImplementedError("--use-builtin-lora: use the reference's own injector on the drop-in DiT "
-                                  "(longcat_video.modules.lora_utils.LoRAModule); this runner ships the fused adapters")
     if args.batch_videos != 1:
         raise NotImplementedError("retrieval-augmented batch TTA needs the sentence-transformer pool (SURVEY §2 #16)")
 
@@ -124,14 +123,27 @@ def main(argv=None):
     for p in dit.parameters():                             # :813-815
         p.requires_grad = False
     target_modules = [m.strip() for m in args.target_modules.split(",") if m.strip()]
-    lora_modules = inject_lora_into_dit(dit, rank=args.lora_rank, alpha=args.lora_alpha, dropout=args.lora_dropout,
-                                        target_modules=target_modules, target_ffn=args.target_ffn,
-                                        target_blocks=args.lora_target_blocks)
-    counts = count_lora_parameters(lora_modules)
+    use_builtin = bool(args.use_builtin_lora)                  # run_lora_tta.py:783, 818-846
+    lora_impl = "builtin" if use_builtin else "custom"
+    if use_builtin:
+        lora_modules = inject_builtin_lora_into_dit(dit, rank=args.lora_rank, alpha=args.lora_alpha, target_modules=target_modules,
+                                                    target_ffn=args.target_ffn, target_blocks=args.lora_target_blocks)
+        counts = count_builtin_lora_parameters(lora_modules)
+        get_params = lambda: get_builtin_lora_parameters(lora_modules)
+        reset_adapters = lambda: reset_builtin_lora_weights(lora_modules)
+        save_adapters = save_builtin_lora_weights
+    else:
+        lora_modules = inject_lora_into_dit(dit, rank=args.lora_rank, alpha=args.lora_alpha, dropout=args.lora_dropout,
+                                            target_modules=target_modules, target_ffn=args.target_ffn,
+                                            target_blocks=args.lora_target_blocks)
+        counts = count_lora_parameters(lora_modules)
+        get_params = lambda: get_lora_parameters(lora_modules)
+        reset_adapters = lambda: reset_lora_weights(lora_modules)
+        save_adapters = save_lora_weights
     if rank == 0:
         exp_config = {
-            "method": "lora_tta_custom",
-            "lora": {"implementation": "custom", "rank": args.lora_rank, "alpha": args.lora_alpha,
+            "method": f"lora_tta_{lora_impl}",
+            "lora": {"implementation": lora_impl, "rank": args.lora_rank, "alpha": args.lora_alpha,
                      "dropout": args.lora_dropout, "target_modules": target_modules,
                      "target_blocks": args.lora_target_blocks, "target_ffn": args.target_ffn,
                      "num_modules": len(lora_modules), "trainable_params": counts["trainable"]},
@@ -166,17 +178,17 @@ def main(argv=None):
             cond, train, val = split_tta_latents(blob["latents"], n_ctx_lat, args.es_holdout_fraction)
             n_tok = (cond.shape[2] + train.shape[2]) * (cond.shape[3] // 2) * (cond.shape[4] // 2)
             choose_gradient_checkpointing(dit, n_tok)
-            reset_lora_weights(lora_modules)
+            reset_adapters()
             es = early_stopper if (early_stopper is not None and val is not None) else None
             if es is not None:
-                params = get_lora_parameters(lora_modules)
+                params = get_params()
                 es.setup(dit, cond, val, blob["prompt_embeds"], blob["prompt_mask"], device=device, dtype=torch.bfloat16,
                          video_id=e["name"], save_fn=lambda: [p.data.clone() for p in params])
             tr = finetune_lora_on_conditioning(dit, lora_modules, cond, train, blob["prompt_embeds"], blob["prompt_mask"],
                                                num_steps=args.num_steps, lr=args.learning_rate,
                                                warmup_steps=args.warmup_steps, weight_decay=args.weight_decay,
                                                max_grad_norm=args.max_grad_norm, device=device, dtype=torch.bfloat16,
-                                               early_stopper=es)
+                                               early_stopper=es, lora_param_fn=get_params)
             result = {"idx": idx, "video_name": e["name"], "video_path": e["path"], "caption": blob.get("caption", ""),
                       "train_time": tr["train_time"], "es_check_time": tr.get("es_check_time", 0.0),
                       "final_loss": tr["losses"][-1] if tr["losses"] else None, "num_train_steps": len(tr["losses"]),
@@ -207,7 +219,7 @@ def main(argv=None):
                                                             frames=frames)
             result["total_time"] = tr["train_time"] + gen_time
             if args.save_lora_weights:
-                save_lora_weights(lora_modules, os.path.join(lora_dir, f"{e['name']}_lora.pt"))
+                save_adapters(lora_modules, os.path.join(lora_dir, f"{e['name']}_lora.pt"))
             print(f"  [{idx}] {e['name']}: train {tr['train_time']:.1f}s loss {result['final_loss']}"
                   + (f" gen {gen_time:.1f}s" if not args.skip_generation else ""))
             all_results.append(result)

@@ -187,3 +187,101 @@ def save_lora_weights(lora_modules: List[LoRALinear], path: str):
         state[f"lora_{i}.down"] = lora.lora_down.weight.detach().cpu()
         state[f"lora_{i}.up"] = lora.lora_up.weight.detach().cpu()
     torch.save(state, path)
+
+
+# =============================================================================================================
+# Upstream-native ("builtin") LoRA: standalone LoRAModule adapters + patched module.forward
+# (lora_experiment/scripts/run_lora_tta.py:104-221, the `--use-builtin-lora` path)
+# =============================================================================================================
+def _build_hooked_forward(module: nn.Module, lora):
+    """`org + lora_up(lora_down(x)) * multiplier * alpha_scale` (run_lora_tta.py:173-182).  The adapter projections are
+    HipLinear modules: the hooked forward stays on the HIP GEMM and the adapter gradients on the skinny-contraction kernel."""
+    def hooked_forward(x, *args, **kwargs):
+        org_output = module.org_forward(x, *args, **kwargs)
+        if lora.use_lora:
+            lx = lora.lora_down(x.to(lora.lora_down.weight.dtype))
+            lx = lora.lora_up(lx)
+            org_output = org_output + lx.to(org_output.dtype) * lora.multiplier * lora.alpha_scale
+        return org_output
+    return hooked_forward
+
+
+def inject_builtin_lora_into_dit(dit: nn.Module, rank: int = 8, alpha: float = 16.0, target_modules=("qkv", "proj"),
+                                 target_ffn: bool = False, target_blocks: str = "all") -> list:
+    """run_lora_tta.py:104-170: n_seperate = 3 for the fused qkv, 2 for kv_linear; same block / module selection and order
+    as the custom injector; the wrapped module keeps its identity (only `.forward` is patched, `.org_forward` remembers it)."""
+    from longcat_video.modules.lora_utils import LoRAModule
+    device = next(dit.parameters()).device
+    dtype = next(dit.parameters()).dtype
+    block_indices = _parse_target_blocks(target_blocks, len(dit.blocks))
+    label = (f"{sorted(block_indices)} ({len(block_indices)}/{len(dit.blocks)})" if block_indices is not None
+             else f"all ({len(dit.blocks)})")
+    print(f"  [builtin] LoRA target blocks: {label}")
+    lora_modules = []
+
+    def _maybe_add(module: nn.Module, name: str, n_sep: int = 1):
+        if not isinstance(module, nn.Linear):
+            return
+        lora = LoRAModule(name, module, multiplier=1.0, lora_dim=rank, alpha=alpha, n_seperate=n_sep).to(device=device, dtype=dtype)
+        lora_modules.append(lora)
+        if not hasattr(module, "org_forward"):
+            module.org_forward = module.forward
+        module.forward = _build_hooked_forward(module, lora)
+
+    for block_idx, block in enumerate(dit.blocks):
+        if block_indices is not None and block_idx not in block_indices:
+            continue
+        if hasattr(block, "attn"):
+            attn = block.attn
+            if "qkv" in target_modules and hasattr(attn, "qkv"):
+                _maybe_add(attn.qkv, f"blocks.{block_idx}.attn.qkv", n_sep=3)
+            if "proj" in target_modules and hasattr(attn, "proj"):
+                _maybe_add(attn.proj, f"blocks.{block_idx}.attn.proj")
+        if hasattr(block, "cross_attn"):
+            xattn = block.cross_attn
+            if "qkv" in target_modules:
+                if hasattr(xattn, "q_linear"):
+                    _maybe_add(xattn.q_linear, f"blocks.{block_idx}.cross_attn.q_linear")
+                if hasattr(xattn, "kv_linear"):
+                    _maybe_add(xattn.kv_linear, f"blocks.{block_idx}.cross_attn.kv_linear", n_sep=2)
+            if "proj" in target_modules and hasattr(xattn, "proj"):
+                _maybe_add(xattn.proj, f"blocks.{block_idx}.cross_attn.proj")
+        if target_ffn and hasattr(block, "ffn"):
+            for layer_name in ("w1", "w2", "w3"):
+                if hasattr(block.ffn, layer_name):
+                    _maybe_add(getattr(block.ffn, layer_name), f"blocks.{block_idx}.ffn.{layer_name}")
+    return lora_modules
+
+
+def get_builtin_lora_parameters(lora_modules) -> List[nn.Parameter]:
+    return [p for lora in lora_modules for p in lora.parameters() if p.requires_grad]
+
+
+def count_builtin_lora_parameters(lora_modules) -> Dict[str, int]:
+    trainable = sum(p.numel() for lora in lora_modules for p in lora.parameters() if p.requires_grad)
+    total = sum(p.numel() for lora in lora_modules for p in lora.parameters())
+    return {"total_lora": total, "trainable": trainable}
+
+
+def reset_builtin_lora_weights(lora_modules):
+    for lora in lora_modules:
+        nn.init.kaiming_uniform_(lora.lora_down.weight, a=math.sqrt(5))
+        ups = lora.lora_up.blocks if hasattr(lora.lora_up, "blocks") else [lora.lora_up]
+        for blk in ups:
+            nn.init.zeros_(blk.weight)
+
+
+def unhook_builtin_lora(dit: nn.Module):
+    for _, module in dit.named_modules():
+        if hasattr(module, "org_forward"):
+            module.forward = module.org_forward
+            delattr(module, "org_forward")
+
+
+def save_builtin_lora_weights(lora_modules, path: str):
+    state = {}
+    for i, lora in enumerate(lora_modules):
+        state[f"lora_{i}.down"] = lora.lora_down.weight.detach().cpu()
+        ups = lora.lora_up.blocks if hasattr(lora.lora_up, "blocks") else [lora.lora_up]
+        state[f"lora_{i}.up"] = torch.cat([u.weight.detach().cpu() for u in ups], 0)
+    torch.save(state, path)

@@ -571,3 +571,69 @@ def test_unconditioned_losses_match_reference_run():
     n_ref = torch.randn(f["latents"].shape, generator=g0, device=DEV, dtype=BF16)
     exp_hs = ((1.0 - 0.25) * f["latents"].to(DEV).float() + 0.25 * n_ref.float()).to(BF16)
     assert torch.equal(calls[0]["hidden_states"], exp_hs)
+
+
+def test_builtin_lora_module_path_forward_and_gradients_match_oracle():
+    """`--use-builtin-lora` (run_lora_tta.py:104-221, row a7): standalone LoRAModule adapters behind a patched `module.forward`
+    (`org + lora_up(lora_down(x)) * multiplier * alpha_scale`, block-diagonal up-projection for the fused qkv / kv linears).
+    Zero-initialised adapters leave the DiT output untouched; with random adapters the prediction and every adapter gradient
+    match torch autograd over the fp32 oracle with the same adapters folded into the weights."""
+    from oracle import dit_oracle as orc
+    from tta.lora import (get_builtin_lora_parameters, inject_builtin_lora_into_dit, reset_builtin_lora_weights,
+                          unhook_builtin_lora)
+    from tta.flow_matching import fm_mse_loss
+    m, cfg, P = _small_dit()
+    for p in m.parameters():
+        p.requires_grad = False
+    B, T, H, W, L = 1, 3, 8, 8, 16
+    hs = _randn(B, 16, T, H, W, seed=50); y = _randn(B, 1, L, 64, seed=51)
+    mask = torch.zeros(B, L, dtype=torch.int64); mask[:, :9] = 1
+    ts = torch.zeros(B, T); ts[:, 1:] = 377.0
+    args = (hs.to(DEV), ts.to(BF16).to(DEV), y.to(DEV), mask.to(DEV))
+    with torch.no_grad():
+        base = m(*args, num_cond_latents=1)
+    mods = inject_builtin_lora_into_dit(m, rank=4, alpha=8.0, target_modules=["qkv", "proj"], target_ffn=False)
+    assert len(mods) == 2 * 5 and all(hasattr(b.attn.qkv, "org_forward") for b in m.blocks)
+    assert [type(mm.lora_up).__name__ for mm in mods[:5]] == ["BlockDiagonalLinear", "HipLinear", "HipLinear", "BlockDiagonalLinear", "HipLinear"]
+    with torch.no_grad():
+        assert torch.equal(m(*args, num_cond_latents=1), base)            # B = 0: no effect, bit for bit
+    g = torch.Generator().manual_seed(6)
+    with torch.no_grad():
+        for p in get_builtin_lora_parameters(mods):
+            p.copy_((torch.randn(p.shape, generator=g) * 0.05).to(BF16))
+    m.train()
+    eps = _randn(B, 16, T - 1, H, W, seed=52); x0 = _randn(B, 16, T - 1, H, W, seed=53)
+    pred = m(*args, num_cond_latents=1)
+    loss = fm_mse_loss(pred, eps.to(DEV), x0.to(DEV), 1)
+    loss.backward()
+    # oracle: fold every adapter into its weight (block-diagonal up-projection = blocks stacked on the output axis, each
+    # reading its own `rank` columns of the down-projection output)
+    names = []
+    for i in range(cfg["depth"]):
+        b = f"blocks.{i}."
+        names += [b + "attn.qkv", b + "attn.proj", b + "cross_attn.q_linear", b + "cross_attn.kv_linear", b + "cross_attn.proj"]
+    P2 = {k: v.float() for k, v in P.items()}
+    leaves = []
+    for n, lm in zip(names, mods):
+        A_ = lm.lora_down.weight.detach().float().cpu().requires_grad_(True)
+        ups = lm.lora_up.blocks if hasattr(lm.lora_up, "blocks") else [lm.lora_up]
+        Bs = [u.weight.detach().float().cpu().requires_grad_(True) for u in ups]
+        r = lm.lora_dim
+        delta = torch.cat([Bk @ A_[k * r:(k + 1) * r] for k, Bk in enumerate(Bs)], 0)
+        P2[n + ".weight"] = P2[n + ".weight"] + lm.multiplier * lm.alpha_scale * delta
+        leaves += [A_] + Bs
+    ref = orc.dit_forward(P2, cfg, hs, ts.to(BF16), y, mask, 1, bf16=False)
+    ref_loss = torch.nn.functional.mse_loss(ref[:, :, 1:], (eps - x0).float())
+    ref_loss.backward()
+    assert rel_l2(pred, ref) < 1e-2 and abs(loss.item() - ref_loss.item()) < 2e-2 * ref_loss.item()
+    got = get_builtin_lora_parameters(mods)
+    assert len(got) == len(leaves)
+    errs = [rel_l2(p.grad, l.grad) for p, l in zip(got, leaves)]
+    print("builtin LoRA grad rel-L2 max / median:", max(errs), sorted(errs)[len(errs) // 2])
+    assert max(errs) < 8e-2 and sorted(errs)[len(errs) // 2] < 3e-2
+    reset_builtin_lora_weights(mods)
+    unhook_builtin_lora(m)
+    assert not any(hasattr(mm, "org_forward") for mm in m.modules())
+    with torch.no_grad():
+        m.eval()
+        assert torch.equal(m(*args, num_cond_latents=1), base)

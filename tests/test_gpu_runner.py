@@ -2,6 +2,8 @@
 inner loop -> KV-cached CFG denoise, with the reference's artifact schemas and resume semantics."""
 import importlib.util
 import json
+
+import torch  # noqa: F401
 from pathlib import Path
 
 import pytest
@@ -38,6 +40,26 @@ def test_runner_end_to_end(tmp_path):
     # resume: nothing left to do, results preserved
     m.main(argv)
     assert len(json.loads((out / "summary.json").read_text())["results"]) == 3
+
+
+def test_runner_builtin_lora_path(tmp_path):
+    """`--use-builtin-lora`: upstream-native LoRAModule adapters behind patched forwards, same loop and artifacts
+    (config.json method `lora_tta_builtin`, run_lora_tta.py:856)."""
+    spec = importlib.util.spec_from_file_location("run_lora_tta_amd", RUNNER)
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    out = tmp_path / "builtin"
+    m.main(["--checkpoint-dir", "synthetic:2:256:64", "--data-dir", "synthetic:2", "--output-dir", str(out), "--num-cond-frames", "5",
+            "--num-frames", "13", "--gen-start-frame", "40", "--tta-total-frames", "33", "--tta-context-frames", "9", "--num-steps", "4",
+            "--es-check-every", "2", "--es-patience", "1", "--num-inference-steps", "2", "--lora-rank", "4", "--lora-alpha", "8",
+            "--use-builtin-lora", "--save-lora-weights", "--no-save-videos"])
+    cfg = json.loads((out / "config.json").read_text())
+    assert cfg["method"] == "lora_tta_builtin" and cfg["lora"]["implementation"] == "builtin" and cfg["lora"]["num_modules"] == 10
+    # rank-4 adapters with n_seperate = 3 / 2 on the fused qkv / kv projections: more down-projection rows than the custom path
+    assert cfg["lora"]["trainable_params"] == 2 * ((3 * 4 * 256 + 768 * 4) + 3 * (4 * 256 + 256 * 4) + (2 * 4 * 256 + 512 * 4))
+    s = json.loads((out / "summary.json").read_text())
+    assert s["num_successful"] == 2 and all(r["final_loss"] > 0 and r["psnr"] > 0 for r in s["results"])
+    w = torch.load(next((out / "lora_weights").glob("*_lora.pt")))
+    assert w["lora_0.down"].shape == (12, 256) and w["lora_0.up"].shape == (768, 4)
 
 
 def _run(rel, argv):
