@@ -90,3 +90,42 @@ def finetune_full_on_conditioning(dit: nn.Module, cond_latents: torch.Tensor, tr
         es_state = early_stopper.state
     optimizer.zero_grad(set_to_none=True)          # 27 GB of gradients are not needed during the continuation
     return {"losses": losses, "train_time": train_time, "es_check_time": es_check_time, "early_stopping_info": es_state}
+
+
+def finetune_full_batch(dit: nn.Module, batch_data: List[Dict], num_steps: int = 10, lr: float = 1e-5, warmup_steps: int = 2,
+                        weight_decay: float = 0.01, max_grad_norm: float = 1.0, device: str = "cuda",
+                        dtype: torch.dtype = torch.bfloat16, optimizer_type: str = "sgd") -> Dict:
+    """run_full_tta.py:230-306: all parameters trained round-robin over several videos (step k takes video k % n; the
+    tensors of a video are moved to the device when its turn comes), no early stopping."""
+    params = [p for p in dit.parameters() if p.requires_grad]
+    if not params:
+        raise ValueError("No trainable parameters found. Did you unfreeze the model?")
+    if optimizer_type == "adamw":
+        optimizer = FusedAdamWClip(params, lr=lr, betas=(0.9, 0.999), weight_decay=weight_decay, eps=1e-8)
+    else:
+        optimizer = FusedSGDClip(params, lr=lr, weight_decay=weight_decay)
+    dit.train()
+    losses = []
+    n_vids = len(batch_data)
+    train_start = time.time()
+    for step in range(num_steps):
+        optimizer.zero_grad(set_to_none=True)
+        if step < warmup_steps and warmup_steps > 0:
+            for pg in optimizer.param_groups:
+                pg["lr"] = lr * (step + 1) / warmup_steps
+        bd = batch_data[step % n_vids]
+        pm = bd["prompt_mask"].to(device) if bd["prompt_mask"] is not None else None
+        loss = compute_flow_matching_loss_conditioned(dit=dit, cond_latents=bd["cond_latents"].to(device),
+                                                      target_latents=bd["train_latents"].to(device),
+                                                      prompt_embeds=bd["prompt_embeds"].to(device), prompt_mask=pm,
+                                                      device=device, dtype=dtype)
+        loss.backward()
+        optimizer.clip_grad_norm_(max_grad_norm)
+        optimizer.step()
+        losses.append(loss.item())
+        del loss
+    torch.cuda.synchronize()
+    train_time = time.time() - train_start
+    dit.eval()
+    optimizer.zero_grad(set_to_none=True)
+    return {"losses": losses, "train_time": train_time, "es_check_time": 0.0, "early_stopping_info": None}

@@ -637,3 +637,56 @@ def test_builtin_lora_module_path_forward_and_gradients_match_oracle():
     with torch.no_grad():
         m.eval()
         assert torch.equal(m(*args, num_cond_latents=1), base)
+
+
+def test_batch_inner_loops_round_robin():
+    """finetune_lora_batch / finetune_full_batch (run_lora_tta.py:558-634, run_full_tta.py:230-306; retrieval-augmented batch
+    TTA trains on the eval video + neighbours, step k on video k % n, tensors moved to the device per step).  With ONE video the
+    batch loop is the single-video loop: identical losses from the same seed.  With two videos the odd steps see the second
+    video: its losses differ from the single-video run exactly there."""
+    from tta.full_tta import finetune_full_batch, finetune_full_on_conditioning, reset_dit_weights, snapshot_base_state
+    from tta.inner_loop import finetune_lora_batch, finetune_lora_on_conditioning
+    from tta.lora import inject_lora_into_dit, reset_lora_weights
+    m, cfg, P = _small_dit()
+    for p in m.parameters():
+        p.requires_grad = False
+    mods = inject_lora_into_dit(m, rank=4, alpha=8.0, target_modules=["qkv", "proj"])
+    g = torch.Generator().manual_seed(9)
+    vids = []
+    for vi in range(2):   # host-resident, like the reference's batch entries; the second video has 3x the latent scale
+        lat = (torch.randn((1, 16, 4, 8, 8), generator=g) * (1.0 + 2.0 * vi)).to(BF16)
+        vids.append(dict(cond_latents=lat[:, :, :2], train_latents=lat[:, :, 2:],
+                         prompt_embeds=torch.randn((1, 1, 16, 64), generator=g).to(BF16), prompt_mask=torch.ones((1, 16), dtype=torch.int64)))
+    kw = dict(num_steps=4, lr=1e-2, warmup_steps=2, device=DEV, dtype=BF16)
+
+    def single():
+        v = vids[0]
+        return finetune_lora_on_conditioning(m, mods, v["cond_latents"].to(DEV), v["train_latents"].to(DEV), v["prompt_embeds"].to(DEV),
+                                             v["prompt_mask"].to(DEV), **kw)["losses"]
+    # the loss reduction adds its per-block partials with fp32 atomics: two runs agree to a few ulps, not bit for bit
+    same = lambda x, y: abs(x - y) <= 1e-2 * abs(y)   # (the steps after the first amplify the ulp-level difference through bf16 weights)
+    # the adapter re-initialisation draws from the global RNG too: seed AFTER the reset
+    reset_lora_weights(mods); torch.manual_seed(1); a = single()
+    reset_lora_weights(mods); torch.manual_seed(1)
+    b = finetune_lora_batch(m, mods, vids[:1], **kw)
+    assert all(same(x, y) for x, y in zip(b["losses"], a)), (a, b["losses"])
+    assert b["early_stopping_info"] is None and b["es_check_time"] == 0.0
+    reset_lora_weights(mods); torch.manual_seed(1)
+    c = finetune_lora_batch(m, mods, vids, **kw)["losses"]
+    assert same(c[0], a[0]) and not same(c[1], a[1]) and all(x == x for x in c)
+    # full-model form
+    from tta.lora import remove_lora_from_dit
+    remove_lora_from_dit(m)
+    for p in m.parameters():
+        p.requires_grad = True
+    base = snapshot_base_state(m)
+    v = vids[0]
+    torch.manual_seed(2)
+    fa = finetune_full_on_conditioning(m, v["cond_latents"].to(DEV), v["train_latents"].to(DEV), v["prompt_embeds"].to(DEV),
+                                       v["prompt_mask"].to(DEV), num_steps=3, lr=1e-3, warmup_steps=1, device=DEV, dtype=BF16)["losses"]
+    reset_dit_weights(m, base); torch.manual_seed(2)
+    fb = finetune_full_batch(m, vids[:1], num_steps=3, lr=1e-3, warmup_steps=1, device=DEV, dtype=BF16)["losses"]
+    assert all(same(x, y) for x, y in zip(fb, fa)), (fa, fb)
+    reset_dit_weights(m, base); torch.manual_seed(2)
+    fc = finetune_full_batch(m, vids, num_steps=3, lr=1e-3, warmup_steps=1, device=DEV, dtype=BF16, optimizer_type="adamw")["losses"]
+    assert same(fc[0], fa[0]) and not same(fc[1], fa[1]) and all(x == x for x in fc), (fa, fc)
