@@ -137,3 +137,16 @@ def test_full_tta_runner_parses_the_sbatch_flag_set():
     assert (d.learning_rate, d.num_steps, d.warmup_steps, d.weight_decay, d.max_grad_norm, d.optimizer) == (1e-5, 10, 2, 0.01, 1.0, "sgd")
     with pytest.raises(SystemExit):
         m.build_parser().parse_args(argv + ["--optimizer", "lion"])
+
+
+def test_nvidia_smi_shim_keeps_the_sbatch_template_alive():
+    """run_sweep.sbatch:24, 254: `nvidia-smi --query-gpu=name,memory.free --format=csv` runs under `set -euo pipefail`; on an
+    AMD node the stand-in under tools/shims must exit 0 and print a CSV header plus one row per GPU."""
+    import os
+    import subprocess
+    env = dict(os.environ, PATH=str(ROOT / "tools" / "shims") + os.pathsep + os.environ.get("PATH", ""))
+    r = subprocess.run(["bash", "-c", "set -euo pipefail; nvidia-smi --query-gpu=name,memory.free --format=csv"], env=env,
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.strip().splitlines()
+    assert lines[0] == "name, memory.free [MiB]" and len(lines) >= 2 and lines[1].endswith("MiB")
