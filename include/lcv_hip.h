@@ -240,6 +240,15 @@ int lcv_fm_noise(const void* x0, const void* eps, const float* sigma, void* out,
  * common.py:485-488.  loss_out: fp32 [1] (zero-filled by callee). dpred nullable. */
 int lcv_fm_mse(const float* pred, const void* eps, const void* x0, float* loss_out, float* dpred,
                int64_t B, int64_t C, int64_t T, int64_t Tc, int64_t HW, void* stream);
+/* Per-sample, no-gradient, deterministic form: loss_out[b] = mean over sample b's target slice.  One launch pair scores
+ * the early stopper's whole anchor set (sigmas x noise draws batched into ONE forward) where the reference runs one forward
+ * and one `.item()` per (sigma, draw): delta_experiment/scripts/common.py:492-559 (the loop at :530-557),
+ * early_stopping.py:296-317.  eps / x0: bf16 [.., C, Tt, HW], sample b at element offset b * {eps,x0}_bstride
+ * (0 = one tensor shared by all samples).  ws: fp32 [B * LCV_FM_MSE_PARTS] scratch; loss_out: fp32 [B]. */
+#define LCV_FM_MSE_PARTS 256
+int lcv_fm_mse_samples(const float* pred, const void* eps, const void* x0, float* loss_out, float* ws,
+                       int64_t B, int64_t C, int64_t T, int64_t Tc, int64_t HW, int64_t eps_bstride,
+                       int64_t x0_bstride, void* stream);
 
 /* ---- fused multi-tensor AdamW + global-norm clip --------------------- */
 /* One descriptor per parameter tensor (device array).  Tensors are cut into 2048-element chunks; a tensor's

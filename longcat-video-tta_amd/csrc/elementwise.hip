@@ -531,6 +531,69 @@ extern "C" int lcv_fm_mse(const float* pred, const void* eps, const void* x0, fl
   return LCV_OK;
 }
 
+// Per-sample form for the early stopper's anchor batch (sigmas x noise draws evaluated in ONE forward): loss[b] = mean over
+// sample b's target slice, no gradient.  Deterministic: LCV_FM_MSE_PARTS fixed-order partial sums per sample, then one block
+// per sample adds them in a fixed tree (no atomics), so a check gives the same floats on every run and the strict `<` of the
+// stopper's bookkeeping is reproducible.  eps / x0 advance by `*_bstride` elements per sample (0 = shared by every sample).
+__global__ __launch_bounds__(256) void fm_mse_parts_kernel(const float* __restrict__ pred, const bf16_t* __restrict__ eps,
+                                                           const bf16_t* __restrict__ x0, float* __restrict__ parts,
+                                                           int64_t C, int T, int Tc, int64_t HW, int64_t eps_bstride,
+                                                           int64_t x0_bstride) {
+  const int b = blockIdx.y;
+  const int Tt = T - Tc;
+  const int64_t per = C * Tt * HW;                       // target elements of one sample
+  const float* pb = pred + (int64_t)b * C * T * HW;
+  const bf16_t* eb = eps + (int64_t)b * eps_bstride;
+  const bf16_t* xb = x0 + (int64_t)b * x0_bstride;
+  float acc = 0.f;
+  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < per; j += (int64_t)gridDim.x * 256) {
+    const int64_t hw = j % HW;
+    const int64_t r = j / HW;
+    const int t = (int)(r % Tt);
+    const int64_t c = r / Tt;
+    const float vt = bfround(bf2f(eb[j]) - bf2f(xb[j]));
+    const float d = pb[(c * T + Tc + t) * HW + hw] - vt;
+    acc += d * d;
+  }
+  __shared__ float red[4];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) parts[(int64_t)b * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(LCV_FM_MSE_PARTS) void fm_mse_finish_kernel(const float* __restrict__ parts,
+                                                                         float* __restrict__ loss, float inv_n) {
+  __shared__ float red[LCV_FM_MSE_PARTS];
+  red[threadIdx.x] = parts[(int64_t)blockIdx.x * LCV_FM_MSE_PARTS + threadIdx.x];
+  __syncthreads();
+  for (int s = LCV_FM_MSE_PARTS / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[blockIdx.x] = red[0] * inv_n;
+}
+
+extern "C" int lcv_fm_mse_samples(const float* pred, const void* eps, const void* x0, float* loss_out, float* ws,
+                                  int64_t B, int64_t C, int64_t T, int64_t Tc, int64_t HW, int64_t eps_bstride,
+                                  int64_t x0_bstride, void* stream) {
+  LCV_CHECK_ARG(pred && eps && x0 && loss_out && ws, "fm_mse_samples: null pointer");
+  LCV_CHECK_ARG(T > Tc && Tc >= 0, "fm_mse_samples: need at least one target frame (T=%ld, Tc=%ld)", (long)T, (long)Tc);
+  LCV_CHECK_ARG(B >= 0 && B <= 65535, "fm_mse_samples: batch %ld out of range", (long)B);
+  const int64_t per = C * (T - Tc) * HW;
+  LCV_CHECK_ARG((eps_bstride == 0 || eps_bstride >= per) && (x0_bstride == 0 || x0_bstride >= per),
+                "fm_mse_samples: sample strides overlap (per-sample target elements %ld)", (long)per);
+  if (B == 0 || per == 0) return LCV_OK;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(fm_mse_parts_kernel, dim3(LCV_FM_MSE_PARTS, (unsigned)B), dim3(256), 0, s, pred, (const bf16_t*)eps,
+                     (const bf16_t*)x0, ws, C, (int)T, (int)Tc, HW, eps_bstride, x0_bstride);
+  LCV_LAUNCH_CHECK("fm_mse_samples (parts)");
+  hipLaunchKernelGGL(fm_mse_finish_kernel, dim3((unsigned)B), dim3(LCV_FM_MSE_PARTS), 0, s, ws, loss_out,
+                     1.0f / (float)per);
+  LCV_LAUNCH_CHECK("fm_mse_samples (finish)");
+  return LCV_OK;
+}
+
 // ---------------------------------------------------------------------------
 // Sinusoidal timestep features (the input of the timestep MLP): out[i, j] = cos(t_i f_j) for j < half, sin(t_i f_j) after,
 // f_j = exp(-ln(max_period) j / half), all fp32 — the one piece of arithmetic the DiT forward still did in torch.

@@ -41,6 +41,7 @@ _SIGNATURES = {
     "lcv_euler_step": [P, P, I64, F32, I, P],
     "lcv_fm_noise": [P, P, P, P, I64, I64, P],
     "lcv_fm_mse": [P, P, P, P, P, I64, I64, I64, I64, I64, P],
+    "lcv_fm_mse_samples": [P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, P],
     "lcv_grad_norm_clip": [P, I64, I64, I, F32, P, P, P],
     "lcv_adamw_step": [P, I64, I64, I, P, F64, F64, F64, F64, F64, I64, P],
     "lcv_sgd_step": [P, I64, I64, I, P, F64, F64, P],

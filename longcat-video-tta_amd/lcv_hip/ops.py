@@ -284,13 +284,33 @@ def fm_noise(x0: torch.Tensor, eps: torch.Tensor, sigma: torch.Tensor) -> torch.
 
 
 def fm_mse(pred: torch.Tensor, eps: torch.Tensor, x0: torch.Tensor, Tc: int, need_grad: bool = True):
-    _req(pred, F32, "fm_mse.pred")
+    _req(pred, F32, "fm_mse.pred"); _req(eps, BF16, "fm_mse.eps"); _req(x0, BF16, "fm_mse.x0")   # the kernel reads raw bf16
     B, C, T, H, W = pred.shape
+    if tuple(eps.shape) != (B, C, T - Tc, H, W) or tuple(x0.shape) != tuple(eps.shape):
+        raise _lib.LcvError(f"fm_mse: eps {tuple(eps.shape)} / x0 {tuple(x0.shape)} do not match pred {tuple(pred.shape)} "
+                            f"with T_cond={Tc}")
     loss = torch.empty((1,), dtype=F32, device=pred.device)
     dpred = torch.empty_like(pred) if need_grad else None
     call("lcv_fm_mse", _ptr(pred.contiguous()), _ptr(eps.contiguous()), _ptr(x0.contiguous()), _ptr(loss),
          _ptr(dpred), B, C, T, Tc, H * W, _stream())
     return loss[0], dpred
+
+
+def fm_mse_samples(pred: torch.Tensor, eps: torch.Tensor, x0: torch.Tensor, Tc: int) -> torch.Tensor:
+    """Per-sample mean((pred[b, :, Tc:] - (eps[b] - x0[b]))^2), fp32 [B], deterministic, no gradient.
+    `eps` / `x0` are bf16 [B or 1, C, Tt, H, W]; a leading 1 is shared by every sample without being expanded."""
+    _req(pred, F32, "fm_mse_samples.pred"); _req(eps, BF16, "fm_mse_samples.eps"); _req(x0, BF16, "fm_mse_samples.x0")
+    B, C, T, H, W = pred.shape
+    per = C * (T - Tc) * H * W
+    for name, t in (("eps", eps), ("x0", x0)):
+        if t.shape[0] not in (1, B) or tuple(t.shape[1:]) != (C, T - Tc, H, W):
+            raise _lib.LcvError(f"fm_mse_samples.{name}: shape {tuple(t.shape)} does not match pred {tuple(pred.shape)} with Tc={Tc}")
+    eps, x0 = eps.contiguous(), x0.contiguous()
+    loss = torch.empty((B,), dtype=F32, device=pred.device)
+    ws = torch.empty((B * 256,), dtype=F32, device=pred.device)
+    call("lcv_fm_mse_samples", _ptr(pred.contiguous()), _ptr(eps), _ptr(x0), _ptr(loss), _ptr(ws), B, C, T, Tc, H * W,
+         per if eps.shape[0] == B and B > 1 else 0, per if x0.shape[0] == B and B > 1 else 0, _stream())
+    return loss
 
 
 # ===================================================================== backward kernels

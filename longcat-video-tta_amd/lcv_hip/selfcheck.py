@@ -24,10 +24,16 @@ def run_smoke():
     ref = orc.dit_forward(P, cfg, hs, ts.to(BF16), y, mask, 1, bf16=True)
     err = (torch.linalg.vector_norm(got.cpu() - ref) / torch.linalg.vector_norm(ref)).item()
     assert err < 1e-2, f"DiT forward differs from the oracle: rel-L2 {err:.3e}"
-    # two denoise steps through the pipeline (CFG + fused Euler update)
+    # two denoise steps through the pipeline (conditioning-frame KV cache, CFG-zero-star, fused Euler update) vs the loop oracle
+    from oracle import pipeline_oracle as porc
     pipe = LongCatVideoPipeline(scheduler=FlowMatchEulerDiscreteScheduler(), dit=dit)
-    lat = torch.randn(1, 16, 3, 8, 8, generator=g).cuda()
-    out = pipe.denoise(lat, y.cuda(), mask.cuda(), y.cuda() * 0, mask.cuda(), num_cond_latents=1,
+    lat = torch.randn(1, 16, 3, 8, 8, generator=g)
+    ne = torch.randn(1, 1, 16, 64, generator=g).to(BF16)
+    out = pipe.denoise(lat.cuda(), y.cuda(), mask.cuda(), ne.cuda(), mask.cuda(), num_cond_latents=1,
                        num_inference_steps=2, guidance_scale=4.0, use_kv_cache=True)
     assert out.shape == lat.shape and torch.isfinite(out).all()
-    print(f"smoke: DiT fwd rel-L2 vs oracle {err:.2e}; 2-step KV-cached CFG denoise finite")
+    want = porc.denoise(P, cfg, lat, y, mask, ne, mask, num_cond_latents=1, num_inference_steps=2, guidance_scale=4.0,
+                        use_kv_cache=True, bf16=True)
+    upd = (torch.linalg.vector_norm((out.cpu() - lat) - (want - lat)) / torch.linalg.vector_norm(want - lat)).item()
+    assert upd < 3e-2, f"2-step denoise update differs from the oracle: rel-L2 {upd:.3e}"
+    print(f"smoke: DiT fwd rel-L2 vs oracle {err:.2e}; 2-step KV-cached CFG denoise update rel-L2 vs oracle {upd:.2e}")

@@ -241,6 +241,12 @@ class FeedForwardSwiGLU(nn.Module):
             return None
         if self.hidden_dim % 32:
             return None
+        if self.w1.weight.requires_grad or self.w3.weight.requires_grad:
+            # trainable gate / up weights (full-model TTA): the fused optimizers update them through raw pointers, which
+            # never bumps `_version`, so a cached interleaved copy would silently go stale — the early stopper's no-grad
+            # anchor checks would then score a model whose FFN is frozen at its pre-TTA values.  No cache, no fusion.
+            self._w13 = self._w13_key = None
+            return None
         key = (self.w1.weight.data_ptr(), self.w3.weight.data_ptr(), self.w1.weight._version, self.w3.weight._version)
         if self._w13 is None or self._w13_key != key:
             F_, K = self.w1.weight.shape

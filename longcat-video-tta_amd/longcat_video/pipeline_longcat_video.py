@@ -103,7 +103,7 @@ class LongCatVideoPipeline:
         do_cfg = guidance_scale > 1.0 and negative_embeds is not None
         sched.set_timesteps(num_inference_steps, sigmas=self.get_timesteps_sigmas(num_inference_steps), device=dev)
         timesteps = sched.timesteps.tolist()
-        latents = latents.to(torch.float32).contiguous()
+        latents = latents.to(torch.float32, copy=True).contiguous()   # the fused step updates in place: never the caller's tensor
         ncl = int(num_cond_latents)
         kv = None
         if ncl > 0 and use_kv_cache:

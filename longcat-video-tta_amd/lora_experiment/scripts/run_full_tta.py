@@ -109,9 +109,7 @@ def main(argv=None):
             es = early_stopper if (early_stopper is not None and val is not None) else None
             if es is not None:                                                          # :724-742 (the stopper snapshots the model itself)
                 es.setup(model=dit, cond_latents=cond, val_latents=val, prompt_embeds=pe, prompt_mask=pm, device=device,
-                         dtype=torch.bfloat16, video_id=e["name"],
-                         forward_fn=lambda hs, ts, ncl: dit(hidden_states=hs, timestep=ts, encoder_hidden_states=pe,
-                                                            encoder_attention_mask=pm, num_cond_latents=ncl))
+                         dtype=torch.bfloat16, video_id=e["name"])
             tr = finetune_full_on_conditioning(dit, cond, train, pe, pm, num_steps=args.num_steps, lr=args.learning_rate,
                                                warmup_steps=args.warmup_steps, weight_decay=args.weight_decay,
                                                max_grad_norm=args.max_grad_norm, device=device, dtype=torch.bfloat16,

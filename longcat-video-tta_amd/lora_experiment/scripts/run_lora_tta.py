@@ -181,9 +181,8 @@ def main(argv=None):
             reset_adapters()
             es = early_stopper if (early_stopper is not None and val is not None) else None
             if es is not None:
-                params = get_params()
                 es.setup(dit, cond, val, blob["prompt_embeds"], blob["prompt_mask"], device=device, dtype=torch.bfloat16,
-                         video_id=e["name"], save_fn=lambda: [p.data.clone() for p in params])
+                         video_id=e["name"])
             tr = finetune_lora_on_conditioning(dit, lora_modules, cond, train, blob["prompt_embeds"], blob["prompt_mask"],
                                                num_steps=args.num_steps, lr=args.learning_rate,
                                                warmup_steps=args.warmup_steps, weight_decay=args.weight_decay,

@@ -9,9 +9,7 @@ DiT (`dit.gradient_checkpointing`), and the gradient reaches delta through the f
 (`lcv_linear_f32_smallm_bwd`) and the modulation-table gradients of `lcv_adaln_modulate_bwd` / `lcv_gate_residual_bwd`.
 The optimizer is the fused clip + AdamW in its fp32 form (delta lives in fp32: run_delta_a.py:104).
 """
-import copy
 import math
-import time
 from typing import Dict, List, Optional
 
 import torch
@@ -21,7 +19,7 @@ import torch.nn.functional as F
 from lcv_hip.ops import FusedAdamWClip
 
 from .early_stopping import AnchoredEarlyStopper
-from .flow_matching import compute_flow_matching_loss_conditioned
+from .inner_loop import _OneVideo, _fm_loss, run_adaptation
 from .lora import _parse_target_blocks
 
 
@@ -190,57 +188,33 @@ class FiLMAdapterWrapper(_HookedWrapper):
 
 def _optimize(wrapper: nn.Module, params: List[nn.Parameter], per_param_clip: bool, cond_latents, train_latents,
               prompt_embeds, prompt_mask, num_steps, lr, device, dtype, early_stopper, train_latents_variants):
+    """AdamW(0.9, 0.999, wd 0.01, eps 1e-15), clip at 1.0, no warm-up (run_delta_a.py:224-305 and its siblings) on the
+    shared engine.  Clipping comes in the three shapes the reference scripts use: per parameter (delta-B,
+    run_delta_b.py:386-388), one global norm, or — bf16 norm weights tuned together with an fp32 delta vector — one fused
+    optimizer per dtype tied by a joint clip coefficient."""
     joint = False
     if per_param_clip:
         groups = [[p] for p in params]
     elif len({p.dtype for p in params}) > 1:
-        # one AdamW + one clip over bf16 and fp32 parameters together (norm weights + a delta vector): one fused optimizer
-        # per dtype, tied by a joint clip coefficient
         groups = [[p for p in params if p.dtype == dt] for dt in (torch.bfloat16, torch.float32)]
         joint = True
     else:
         groups = [params]
     opts = [FusedAdamWClip(g, lr=lr, betas=(0.9, 0.999), weight_decay=0.01, eps=1e-15) for g in groups]
-    if train_latents_variants is None:
-        train_latents_variants = [{"latents": train_latents, "name": "orig"}]
 
-    def _save_fn():
-        return [copy.deepcopy(p.data) for p in params]
-
-    wrapper.train()
-    losses, es_check_time = [], 0.0
-    for step in range(num_steps):
-        for o in opts:
-            o.zero_grad()
-        vi = torch.randint(0, len(train_latents_variants), (1,)).item()
-        loss = compute_flow_matching_loss_conditioned(dit=wrapper, cond_latents=cond_latents,
-                                                      target_latents=train_latents_variants[vi]["latents"],
-                                                      prompt_embeds=prompt_embeds, prompt_mask=prompt_mask,
-                                                      device=device, dtype=dtype)
-        loss.backward()
+    def clip_and_step():
+        live = [o for o in opts if any(p.grad is not None for p in o.params)]
         if joint:
             FusedAdamWClip.joint_clip_grad_norm_(opts, 1.0)
-        for o in opts:
-            if any(p.grad is not None for p in o.params):
-                if not joint:
-                    o.clip_grad_norm_(1.0)
-                o.step()
-        losses.append(loss.item())
-        if early_stopper is not None:
-            t0 = time.time()
-            should_stop, es_info = early_stopper.step(step + 1, save_fn=_save_fn)
-            es_check_time += time.time() - t0
-            if should_stop:
-                print(f"  Early stopping at step {step + 1}: {es_info}")
-                break
-    es_state = None
-    if early_stopper is not None:
-        def _restore(snap):
-            for p, s in zip(params, snap):
-                p.data.copy_(s)
-        early_stopper.restore(restore_fn=_restore)
-        es_state = early_stopper.state
-    return losses, es_check_time, es_state
+        for o in live:
+            if not joint:
+                o.clip_grad_norm_(1.0)
+            o.step()
+
+    feed = _OneVideo(cond_latents, train_latents, prompt_embeds, prompt_mask, train_latents_variants)
+    out = run_adaptation(wrapper, params, opts, _fm_loss(wrapper, feed, device, dtype), clip_and_step, num_steps,
+                         early_stopper=early_stopper, finish_eval=False)
+    return out["losses"], out["es_check_time"], out["early_stopping_info"]
 
 
 def optimize_delta_a(wrapper: DeltaAWrapper, cond_latents, train_latents, prompt_embeds, prompt_mask, num_steps: int = 20,

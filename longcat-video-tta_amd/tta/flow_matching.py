@@ -38,6 +38,9 @@ class _FMMse(torch.autograd.Function):
 def fm_mse_loss(pred: torch.Tensor, noise: torch.Tensor, target: torch.Tensor, T_cond: int) -> torch.Tensor:
     """mean((pred[:, :, T_cond:] - (noise - target))^2) in fp32; differentiable w.r.t. pred."""
     pred = pred.to(torch.float32).contiguous()
+    # the kernel evaluates the reference's `(noise - target)` in bf16 (common.py:486 on bf16 latents); fp32 latents
+    # (an fp32 VAE, pre-encoded blobs saved in fp32) are brought to that dtype here rather than reinterpreted
+    noise, target = noise.to(torch.bfloat16), target.to(torch.bfloat16)
     if torch.is_grad_enabled() and pred.requires_grad:
         return _FMMse.apply(pred, noise, target, T_cond)
     loss, _ = ops.fm_mse(pred, noise, target, T_cond, need_grad=False)

@@ -225,12 +225,9 @@ def run_delta_method(args, method: str, make_wrapper: Callable, optimize_fn: Cal
             pe, pm = blob["prompt_embeds"], blob["prompt_mask"]
             es = early_stopper if (early_stopper is not None and val is not None) else None
             if es is not None:
-                import copy
+                # the wrapper is called directly, so the stopper scores its whole anchor set in one batched forward
                 es.setup(model=wrapper, cond_latents=cond, val_latents=val, prompt_embeds=pe, prompt_mask=pm, device=device,
-                         dtype=torch.bfloat16,
-                         forward_fn=lambda hs, ts, ncl: wrapper(hidden_states=hs, timestep=ts, encoder_hidden_states=pe,
-                                                                encoder_attention_mask=pm, num_cond_latents=ncl),
-                         video_id=e["name"], save_fn=lambda: [copy.deepcopy(p.data) for p in params_of(wrapper)])
+                         dtype=torch.bfloat16, video_id=e["name"])
             t0 = time.time()
             opt = optimize_fn(wrapper, cond, train, pe, pm, device, es)
             torch.cuda.synchronize()

@@ -40,8 +40,9 @@ def bf16_round(t: torch.Tensor) -> torch.Tensor:
 
 
 # --------------------------------------------------------------------------- RoPE
-def rope_angles_3d(grid: Tuple[int, int, int], head_dim: int = 128, base: float = 10000.0) -> torch.Tensor:
-    """[T*H*W, head_dim] angles, each frequency repeated for its (2i, 2i+1) pair; axis order t | h | w."""
+def rope_angles_3d(grid: Tuple[int, int, int], head_dim: int = 128, base: float = 10000.0, device=None) -> torch.Tensor:
+    """[T*H*W, head_dim] angles, each frequency repeated for its (2i, 2i+1) pair; axis order t | h | w.
+    Built on the CPU (so the table is the same whichever device evaluates the oracle), then moved."""
     T, H, W = grid
     dim_t = head_dim - 4 * (head_dim // 6)
     dim_h = 2 * (head_dim // 6)
@@ -58,7 +59,7 @@ def rope_angles_3d(grid: Tuple[int, int, int], head_dim: int = 128, base: float 
         fh[None, :, None, :].expand(T, H, W, dim_h),
         fw[None, None, :, :].expand(T, H, W, dim_w),
     ], dim=-1)
-    return ang.reshape(T * H * W, head_dim)
+    return ang.reshape(T * H * W, head_dim).to(device)
 
 
 def rope_cos_sin_table(grid: Tuple[int, int, int], head_dim: int = 128) -> torch.Tensor:
@@ -105,10 +106,19 @@ def linear(x, w, b=None, rnd=_id):
 
 
 def sdpa(q, k, v, scale, rnd=_id):
-    """q [B,H,Nq,D], k/v [B,H,Nk,D] -> [B,H,Nq,D]; softmax in fp32."""
-    s = (q.float() @ k.float().transpose(-1, -2)) * scale
-    p = torch.softmax(s, dim=-1)
-    return rnd(p @ v.float())
+    """q [B,H,Nq,D], k/v [B,H,Nk,D] -> [B,H,Nq,D]; softmax in fp32.  Heads are walked in groups when the score
+    matrix would not fit (full-size clips evaluated with this file on the GPU box's card: tests/test_gpu_denoise_parity.py)."""
+    B, H, Nq, _ = q.shape
+    per_head = B * Nq * k.shape[2] * 4
+    step = max(1, min(H, int((6 << 30) // max(per_head, 1))))
+    outs = []
+    for h0 in range(0, H, step):
+        s = (q[:, h0:h0 + step].float() @ k[:, h0:h0 + step].float().transpose(-1, -2)) * scale
+        p = torch.softmax(s, dim=-1)
+        del s
+        outs.append(rnd(p @ v[:, h0:h0 + step].float()))
+        del p
+    return outs[0] if len(outs) == 1 else torch.cat(outs, dim=1)
 
 
 # --------------------------------------------------------------------------- block pieces
@@ -125,10 +135,12 @@ def self_attention(P: Dict[str, torch.Tensor], pre: str, x, shape, num_cond_late
     if kv_cache is not None:
         # KV-cached denoise step: cached cond K (pre-RoPE) / V in front, positions continue after them
         k_c, v_c = kv_cache
+        if k_c.shape[0] != B:  # one cached conditioning clip shared by the CFG pair
+            k_c, v_c = k_c.expand(B, -1, -1, -1), v_c.expand(B, -1, -1, -1)
         T, Hh, Ww = shape
         n_c = k_c.shape[2]
         t_c = n_c // (Hh * Ww)
-        ang = rope_angles_3d((T + t_c, Hh, Ww), D)
+        ang = rope_angles_3d((T + t_c, Hh, Ww), D, device=x.device)
         k_full = torch.cat([k_c.float(), k.float()], dim=2)
         v_full = torch.cat([v_c.float(), v.float()], dim=2)
         k_full = apply_rope(k_full, ang, rnd)
@@ -136,7 +148,7 @@ def self_attention(P: Dict[str, torch.Tensor], pre: str, x, shape, num_cond_late
         o = sdpa(q, k_full, v_full, scale, rnd)
     else:
         kv = (k.clone(), v.clone()) if return_kv else None
-        ang = rope_angles_3d(tuple(shape), D)
+        ang = rope_angles_3d(tuple(shape), D, device=x.device)
         q, k = apply_rope(q, ang, rnd), apply_rope(k, ang, rnd)
         if num_cond_latents is not None and num_cond_latents > 0:
             nc = num_cond_latents * (N // shape[0])
@@ -176,7 +188,7 @@ def cross_attention(P, pre, x, y, y_seqlens: Sequence[int], num_cond_latents, sh
     o = torch.stack(outs, 0)
     o = linear(o, P[pre + "proj.weight"], P.get(pre + "proj.bias"), rnd)
     if nc > 0:
-        o = torch.cat([torch.zeros(B, nc, C, dtype=o.dtype), o], dim=1)
+        o = torch.cat([torch.zeros(B, nc, C, dtype=o.dtype, device=o.device), o], dim=1)
     return o
 
 
@@ -221,7 +233,7 @@ def block_forward(P, pre, x, y, t, y_seqlens, shape, num_cond_latents, num_heads
 # --------------------------------------------------------------------------- embedders / head
 def timestep_embedding(t: torch.Tensor, dim: int = 256, max_period: float = 10000.0) -> torch.Tensor:
     half = dim // 2
-    freqs = torch.exp(-math.log(max_period) * torch.arange(half, dtype=torch.float32) / half)
+    freqs = torch.exp(-math.log(max_period) * torch.arange(half, dtype=torch.float32) / half).to(t.device)
     args = t[:, None].float() * freqs[None]
     return torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
 
@@ -272,9 +284,15 @@ def pack_text(y_emb: torch.Tensor, mask: Optional[torch.Tensor]):
 
 
 def dit_forward(P: Dict[str, torch.Tensor], cfg: dict, hidden_states, timestep, encoder_hidden_states,
-                encoder_attention_mask=None, num_cond_latents=0, bf16: bool = True, t_delta=None) -> torch.Tensor:
+                encoder_attention_mask=None, num_cond_latents=0, bf16: bool = True, t_delta=None,
+                return_kv: bool = False, kv_cache_dict=None, skip_crs_attn: bool = False):
     """Full forward following run_delta_a.py:134-217.  cfg: depth, num_heads, patch_size, out_channels,
-    text_tokens_zero_pad."""
+    text_tokens_zero_pad.
+
+    `return_kv` / `skip_crs_attn` / `kv_cache_dict` are the three switches the pipeline's conditioning-frame KV
+    cache uses [assumed-from-upstream]: the clean conditioning latents pass once at t = 0 without text
+    cross-attention and every block keeps its (K pre-RoPE, V); a denoise step then runs over the noise tokens
+    only, with the cached cond K/V in front of the keys and RoPE positions continuing after them."""
     rnd = bf16_round if bf16 else _id
     B, _, T, H, W = hidden_states.shape
     pt, ph, pw = cfg["patch_size"]
@@ -294,11 +312,20 @@ def dit_forward(P: Dict[str, torch.Tensor], cfg: dict, hidden_states, timestep, 
         y = y * mask[:, None, :, None].float()
         mask = (mask * 0 + 1).to(mask.dtype)
     y, y_seqlens = pack_text(y, mask)
+    kv_out = {} if return_kv else None
     for i in range(cfg["depth"]):
-        x = block_forward(P, f"blocks.{i}.", x, y, t, y_seqlens, (N_t, N_h, N_w), num_cond_latents,
-                          cfg["num_heads"], rnd)
+        kvc = None if kv_cache_dict is None else kv_cache_dict[i]
+        r = block_forward(P, f"blocks.{i}.", x, y, t, y_seqlens, (N_t, N_h, N_w), num_cond_latents,
+                          cfg["num_heads"], rnd, kv_cache=kvc, return_kv=return_kv, skip_crs_attn=skip_crs_attn)
+        if return_kv:
+            x, kv_out[i] = r
+        else:
+            x = r
     x = final_layer(P, x, t, (N_t, N_h, N_w), rnd)
-    return unpatchify(x, N_t, N_h, N_w, (pt, ph, pw), cfg["out_channels"]).float()
+    out = unpatchify(x, N_t, N_h, N_w, (pt, ph, pw), cfg["out_channels"]).float()
+    if return_kv:
+        return out, kv_out
+    return out
 
 
 # --------------------------------------------------------------------------- synthetic weights

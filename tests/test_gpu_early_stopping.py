@@ -1,0 +1,170 @@
+"""GPU: the early stopper's batched anchor scoring and the shared inner-loop engine.
+
+The reference scores its anchor set (sigmas x noise draws) with one no-grad forward and one `.item()` per pair
+(delta_experiment/scripts/common.py:492-559, early_stopping.py:296-317).  The build evaluates the whole set as ONE resident
+batch (`tta/early_stopping.py::_AnchorSet`, `lcv_fm_mse_samples`).  Checked here: the per-sample kernel against torch, bit
+reproducibility, equality of the batched loss with the sequential reference form (`compute_flow_matching_loss_conditioned_fixed`,
+itself pinned by the reference fixture in test_gpu_backward.py), the snapshot / restore contract of the loop, and the
+round-1 advisor finding (the early stopper must score the UPDATED weights in full-model TTA)."""
+import time
+
+import pytest
+import torch
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+BF16 = torch.bfloat16
+DEV = "cuda"
+
+
+def _small_dit(seed=21, depth=2):
+    from longcat_video.modules.longcat_video_dit import LongCatVideoTransformer3DModel
+    m = LongCatVideoTransformer3DModel(device=DEV, dtype=BF16, hidden_size=256, depth=depth, num_heads=2, caption_channels=64,
+                                       adaln_tembed_dim=64).init_synthetic_(seed, std=0.05)
+    return m.eval()
+
+
+def _clip(seed=5, T=5, h=8, w=12):
+    g = torch.Generator().manual_seed(seed)
+    lat = torch.randn(1, 16, T, h, w, generator=g).to(BF16).to(DEV)
+    pe = torch.randn(1, 1, 16, 64, generator=g).to(BF16).to(DEV)
+    pm = torch.ones(1, 16, dtype=torch.int64, device=DEV); pm[:, 11:] = 0
+    return lat, pe, pm
+
+
+def test_fm_mse_samples_matches_torch_and_is_deterministic():
+    from lcv_hip import ops
+    g = torch.Generator().manual_seed(1)
+    B, C, T, Tc, H, W = 6, 16, 5, 3, 12, 20
+    pred = torch.randn(B, C, T, H, W, generator=g).to(DEV)
+    eps = torch.randn(B, C, T - Tc, H, W, generator=g).to(BF16).to(DEV)
+    x0 = torch.randn(1, C, T - Tc, H, W, generator=g).to(BF16).to(DEV)
+    got = ops.fm_mse_samples(pred, eps, x0, Tc)
+    vt = (eps - x0).float()                                              # bf16 subtraction, then widened (common.py:486)
+    ref = ((pred[:, :, Tc:] - vt) ** 2).flatten(1).mean(1)
+    assert got.shape == (B,) and torch.allclose(got, ref, rtol=2e-6, atol=0)
+    again = ops.fm_mse_samples(pred, eps, x0, Tc)
+    assert torch.equal(got, again)                                       # fixed-order partial sums: bit-reproducible
+    # per-sample x0 (no sharing) and the batch-1 form agree with the scalar kernel's mean
+    x0b = x0.expand(B, -1, -1, -1, -1).contiguous()
+    assert torch.equal(ops.fm_mse_samples(pred, eps, x0b, Tc), got)
+    scalar, _ = ops.fm_mse(pred, eps, x0b, Tc, need_grad=False)
+    assert abs(scalar.item() - got.mean().item()) < 1e-6 * got.mean().item() + 1e-9
+    with pytest.raises(Exception):
+        ops.fm_mse_samples(pred, eps.float(), x0, Tc)                    # fp32 noise is refused, not reinterpreted
+
+
+def test_batched_anchor_loss_equals_the_sequential_reference_form():
+    from tta.early_stopping import AnchoredEarlyStopper
+    from tta.flow_matching import compute_flow_matching_loss_conditioned_fixed
+    dit = _small_dit()
+    lat, pe, pm = _clip()
+    cond, val = lat[:, :, :3], lat[:, :, 3:]
+    es = AnchoredEarlyStopper(check_every=2, patience=2)
+    es.setup(dit, cond, val, pe, pm, device=DEV, dtype=BF16, video_id="v_ApplyEyeMakeup_g01_c01")
+    assert es._anchors.size == 6 and len(es.fixed_noises) == 2 and es.loss_history == [(0, es.best_loss)]
+    seq = compute_flow_matching_loss_conditioned_fixed(dit, cond, val, pe, pm, es.anchor_sigmas, es.fixed_noises, device=DEV,
+                                                       dtype=BF16)
+    print(f"anchor loss batched {es.best_loss:.7f} vs sequential {seq:.7f}")
+    assert abs(es.best_loss - seq) <= 2e-6 * abs(seq)     # same per-sample predictions; only the MSE summation order differs
+    assert es._compute_anchor_loss() == es.best_loss       # deterministic
+    # the caller-supplied forward protocol (forward_fn(hidden_states, timestep, N_cond)) scores the same set one by one
+    es2 = AnchoredEarlyStopper()
+    es2.setup(dit, cond, val, pe, pm, device=DEV, dtype=BF16, video_id="v_ApplyEyeMakeup_g01_c01",
+              forward_fn=lambda hs, ts, n: dit(hidden_states=hs, timestep=ts, encoder_hidden_states=pe,
+                                               encoder_attention_mask=pm, num_cond_latents=n))
+    assert abs(es2.best_loss - es.best_loss) <= 2e-6 * abs(seq)
+
+
+def test_lora_loop_with_early_stopping_restores_the_best_snapshot():
+    from tta.early_stopping import AnchoredEarlyStopper, ParamSnapshot
+    from tta.inner_loop import finetune_lora_on_conditioning
+    from tta.lora import get_lora_parameters, inject_lora_into_dit
+    dit = _small_dit(23)
+    for p in dit.parameters():
+        p.requires_grad = False
+    mods = inject_lora_into_dit(dit, rank=4, alpha=8.0, target_modules=["qkv", "proj"])
+    params = get_lora_parameters(mods)
+    lat, pe, pm = _clip(7, T=6)
+    cond, train, val = lat[:, :, :2], lat[:, :, 2:5], lat[:, :, 5:]
+    es = AnchoredEarlyStopper(check_every=2, patience=1)
+    es.setup(dit, cond, val, pe, pm, device=DEV, dtype=BF16, video_id="clip7")
+    assert isinstance(es.best_state, ParamSnapshot) and es.best_state.covers(params)
+    torch.manual_seed(0)
+    res = finetune_lora_on_conditioning(dit, mods, cond, train, pe, pm, num_steps=8, lr=5e-2, warmup_steps=2, device=DEV,
+                                        dtype=BF16, early_stopper=es)
+    info = res["early_stopping_info"]
+    assert set(res) == {"losses", "train_time", "es_check_time", "early_stopping_info"}
+    assert len(res["losses"]) in (2, 4, 6, 8) and all(x == x for x in res["losses"])
+    assert info["total_checks"] == 1 + len(res["losses"]) // 2 and res["es_check_time"] > 0
+    assert [s for s, _ in info["loss_history"]] == list(range(0, len(res["losses"]) + 1, 2))
+    assert not dit.training
+    # the adapters now hold the best snapshot: scoring them again reproduces the recorded best loss exactly
+    assert abs(es._compute_anchor_loss() - info["best_loss"]) <= 1e-6 * info["best_loss"]
+    if info["stopped_early"]:
+        assert len(res["losses"]) < 8 and info["best_step"] < len(res["losses"])
+
+
+def test_full_model_anchor_checks_score_the_updated_weights():
+    """Round-1 advisor finding: the fused optimizers write parameters through raw pointers (no `_version` bump), so a cached
+    interleaved (w1, w3) copy built by the stopper's first no-grad forward would freeze the FFN at its pre-TTA values in
+    every later check.  After N SGD steps the stopper's score must equal the score of a FRESH model carrying the updated
+    weights."""
+    from tta.early_stopping import AnchoredEarlyStopper
+    from tta.full_tta import finetune_full_on_conditioning
+    dit = _small_dit(29)
+    for p in dit.parameters():
+        p.requires_grad = True
+    lat, pe, pm = _clip(9, T=6)
+    cond, train, val = lat[:, :, :2], lat[:, :, 2:5], lat[:, :, 5:]
+    es = AnchoredEarlyStopper(check_every=3, patience=10)
+    es.setup(dit, cond, val, pe, pm, device=DEV, dtype=BF16, video_id="clip9")
+    before = es.best_loss
+    torch.manual_seed(1)
+    res = finetune_full_on_conditioning(dit, cond, train, pe, pm, num_steps=3, lr=3e-2, warmup_steps=1, device=DEV, dtype=BF16,
+                                        early_stopper=None)
+    assert len(res["losses"]) == 3
+    after = es._compute_anchor_loss()
+    fresh = _small_dit(1)
+    fresh.load_state_dict(dit.state_dict())
+    for p in fresh.parameters():
+        p.requires_grad = False                       # frozen weights: this model takes the fused (w1, w3) path
+    es_fresh = AnchoredEarlyStopper(check_every=3, patience=10)
+    es_fresh.setup(fresh, cond, val, pe, pm, device=DEV, dtype=BF16, video_id="clip9")
+    print(f"anchor loss before {before:.6f}, after 3 SGD steps {after:.6f}, fresh model with the same weights {es_fresh.best_loss:.6f}")
+    assert abs(after - before) > 1e-4 * before                     # the weights really moved
+    assert abs(after - es_fresh.best_loss) <= 3e-3 * es_fresh.best_loss   # fused vs unfused SwiGLU path: bf16 rounding only
+
+
+def test_anchor_check_time_batched_vs_sequential_full_width():
+    """ES check time before / after: 6 anchor samples at the reference's 480p operating point for the
+    held-out clip (3 context + 1 held-out latent frame = 6 240 tokens), full width, 4 blocks."""
+    from longcat_video.modules.longcat_video_dit import LongCatVideoTransformer3DModel
+    from tta.early_stopping import AnchoredEarlyStopper
+    from tta.flow_matching import compute_flow_matching_loss_conditioned_fixed
+    dit = LongCatVideoTransformer3DModel(device=DEV, dtype=BF16, depth=4).init_synthetic_(3).eval()
+    for p in dit.parameters():
+        p.requires_grad = False
+    g = torch.Generator().manual_seed(2)
+    lat = torch.randn(1, 16, 4, 60, 104, generator=g).to(BF16).to(DEV)
+    pe = torch.randn(1, 1, 512, 4096, generator=g).to(BF16).to(DEV)
+    pm = torch.zeros(1, 512, dtype=torch.int64, device=DEV); pm[:, :77] = 1
+    cond, val = lat[:, :, :3], lat[:, :, 3:]
+    es = AnchoredEarlyStopper()
+    es.setup(dit, cond, val, pe, pm, device=DEV, dtype=BF16, video_id="timing")
+
+    def clock(fn, n=3):
+        fn(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            out = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n, out
+    t_b, l_b = clock(es._compute_anchor_loss)
+    t_s, l_s = clock(lambda: compute_flow_matching_loss_conditioned_fixed(dit, cond, val, pe, pm, es.anchor_sigmas,
+                                                                          es.fixed_noises, device=DEV, dtype=BF16))
+    print(f"ES check, 6 samples x 6 240 tokens x 4 blocks: sequential {t_s * 1e3:.1f} ms, batched {t_b * 1e3:.1f} ms "
+          f"({t_s / t_b:.2f}x); losses {l_s:.6f} / {l_b:.6f}")
+    assert abs(l_b - l_s) <= 1e-5 * abs(l_s)
+    assert t_b < 1.15 * t_s
