@@ -403,6 +403,11 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnFwdPara
   }
 }
 
+int attn_fwd_pipe_launch(const void* q, const void* k, const void* v, void* o, float* lse, int64_t B, int64_t H, int64_t Nq,
+                         int64_t Nk, int64_t q_sb, int64_t q_sn, int64_t q_sh, int64_t k_sb, int64_t k_sn, int64_t k_sh,
+                         int64_t v_sb, int64_t v_sn, int64_t v_sh, int64_t o_sb, int64_t o_sn, int64_t o_sh, float scale,
+                         int xcd_ok, hipStream_t s);   // attn_fwd_pipe.hip
+
 extern "C" int lcv_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int64_t B,
                             int64_t H, int64_t Nq, int64_t Nk, int64_t q_sb, int64_t q_sn, int64_t q_sh,
                             int64_t k_sb, int64_t k_sn, int64_t k_sh, int64_t v_sb, int64_t v_sn,
@@ -446,6 +451,13 @@ extern "C" int lcv_attn_fwd(const void* q, const void* k, const void* v, void* o
   // Q pre-scaled into log2 units (scale = ln 2): the multiply-free softmax body
   const bool unit = p.scale_log2e > 1.0f - 4e-7f && p.scale_log2e < 1.0f + 4e-7f;
   int rc;
+  const char* pe2 = getenv("LCV_ATTN_PIPE");  // A/B knob: 0 = the phase-ordered kernel of this file instead of attn_fwd_pipe.hip
+  // (its LDS-DMA addresses are a scalar base + 32-bit per-lane byte offsets: one (batch, head)'s rows must span < 4 GiB)
+  const bool span32 = (uint64_t)Nk * (uint64_t)(k_sn > v_sn ? k_sn : v_sn) * 2 < (1ull << 32) &&
+                      (uint64_t)Nq * (uint64_t)q_sn * 2 < (1ull << 32);
+  if (unit && Nk > 512 && span32 && !(pe2 && pe2[0] == '0') && prio == 0 && var == 1)
+    return attn_fwd_pipe_launch(q, k, v, o, lse, B, H, Nq, Nk, q_sb, q_sn, q_sh, k_sb, k_sn, k_sh, v_sb, v_sn, v_sh, o_sb, o_sn,
+                                o_sh, scale, !(xe && xe[0] == '0'), (hipStream_t)stream);
   if (Nk <= 512) rc = launch(attn_fwd_kernel<NW, 0, true, 0>);
   else if (prio == 1) rc = launch(attn_fwd_kernel<NW, 1, false, 0>);
   else if (var == 0) rc = launch(attn_fwd_kernel<NW, 0, false, 0>);
