@@ -47,15 +47,14 @@ int main(int argc, char** argv) {
   run(); hipDeviceSynchronize();
   std::vector<unsigned long long> h(512);
   hipMemcpy(h.data(), dbg, 512 * 8, hipMemcpyDeviceToHost);
-  const char* names[] = {"phase1(QK+exp)", "phase2(PV+max)", "settle", "vmcnt(0)", "barrier", "next-iter head"};
   for (int w = 0; w < 2; ++w) {
-    printf("wave %d: per iteration [phase1 phase2 settle vmcnt barrier | total]\n", w ? 4 : 0);
+    printf("wave %d: per iteration [phase1 | vmcnt+barrier | phase2 | settle] total, then gap to the next iteration's first stamp\n", w ? 4 : 0);
     for (int it = 0; it < 7; ++it) {
       const unsigned long long* s = &h[w * 256 + it * 8];
       if (!s[0]) continue;
       printf("  it %d:", 200 + it);
-      for (int i = 0; i < 5; ++i) printf(" %5llu", s[i + 1] - s[i]);
-      printf(" | %5llu   (to next iteration's first stamp: %llu)\n", s[5] - s[0], h[w * 256 + (it + 1) * 8] - s[5]);
+      for (int i = 0; i < 4; ++i) printf(" %5llu", s[i + 1] - s[i]);
+      printf(" | %5llu   +%llu\n", s[4] - s[0], h[w * 256 + (it + 1) * 8] - s[4]);
     }
   }
   printf("wave4 - wave0 at iteration 200 start: %lld cycles\n", (long long)(h[256] - h[0]));

@@ -19,15 +19,17 @@ for (B, H, Nq, Nk) in shapes:
     q = (rmsn(torch.randn(B, Nq, H, D, device=dev, generator=g)) * (D ** -0.5 * math.log2(math.e))).to(bf)
     k = rmsn(torch.randn(B, Nk, H, D, device=dev, generator=g)).to(bf)
     v = torch.randn(B, Nk, H, D, device=dev, generator=g).to(bf)
-    outs = {}; res = {"0": [], "1": []}
+    VARS = ("0", "1", "1p1", "1p2", "1p3")
+    outs = {}; res = {v: [] for v in VARS}
     for rep in range(3):
-        for var in ("0", "1"):
-            os.environ["LCV_ATTN_PIPE"] = var
+        for var in VARS:
+            os.environ["LCV_ATTN_PIPE"] = var[0]
+            os.environ["LCV_ATTN_PIPE_PRIO"] = var[2] if len(var) > 1 else "0"
             o = torch.empty(B, Nq, H, D, device=dev, dtype=bf)
             res[var].append(timeit(lambda: ops.attention(q, k, v, math.log(2.0), out=o)))
             outs[var] = o
     fl = 4.0 * B * H * Nq * Nk * D
-    for var in ("0", "1"):
+    for var in VARS:
         print(f"B{B} H{H} Nq{Nq} Nk{Nk} pipe={var}: best {min(res[var]):.2f} ms = {fl/min(res[var])/1e9:.0f} TF/s  all {[round(x,2) for x in res[var]]}", flush=True)
     d = outs["0"].float() - outs["1"].float()
     print("   rel_l2 pipe vs phase-ordered:", (d.norm() / outs["0"].float().norm()).item(), "max abs", d.abs().max().item(), "finite", bool(torch.isfinite(outs["1"].float()).all()), flush=True)
