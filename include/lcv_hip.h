@@ -137,6 +137,10 @@ int lcv_attn_fwd(const void* q, const void* k, const void* v, void* o, float* ls
                  int64_t v_sb, int64_t v_sn, int64_t v_sh,
                  int64_t o_sb, int64_t o_sn, int64_t o_sh,
                  float scale, void* stream);
+/* Which kernel the most recent lcv_attn_fwd call of this thread launched (a static string, never NULL; "none" before the
+ * first call): the library picks the body by shape and scale (software-pipelined self-attention body, phase-ordered body,
+ * short-key cross-attention body), and bench.py labels its roofline object with what actually ran. */
+const char* lcv_attn_fwd_last_kernel(void);
 /* Backward (two passes, no atomics: dK/dV per 128-key workgroup, dQ per 256-query workgroup; see csrc/attn_bwd.hip).
  * d_o shares o's strides.  delta_ws: fp32 workspace [B,H,Nq].  accumulate_kv != 0 adds into the existing dk/dv
  * (second region of the conditioning split).  dq/dk/dv are addressed like q/k/v with their own strides. */

@@ -408,6 +408,9 @@ int attn_fwd_pipe_launch(const void* q, const void* k, const void* v, void* o, f
                          int64_t v_sb, int64_t v_sn, int64_t v_sh, int64_t o_sb, int64_t o_sn, int64_t o_sh, float scale,
                          int xcd_ok, hipStream_t s);   // attn_fwd_pipe.hip
 
+static thread_local const char* g_last_attn_kernel = "none";
+extern "C" const char* lcv_attn_fwd_last_kernel(void) { return g_last_attn_kernel; }
+
 extern "C" int lcv_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int64_t B,
                             int64_t H, int64_t Nq, int64_t Nk, int64_t q_sb, int64_t q_sn, int64_t q_sh,
                             int64_t k_sb, int64_t k_sn, int64_t k_sh, int64_t v_sb, int64_t v_sn,
@@ -455,14 +458,16 @@ extern "C" int lcv_attn_fwd(const void* q, const void* k, const void* v, void* o
   // (its LDS-DMA addresses are a scalar base + 32-bit per-lane byte offsets: one (batch, head)'s rows must span < 4 GiB)
   const bool span32 = (uint64_t)Nk * (uint64_t)(k_sn > v_sn ? k_sn : v_sn) * 2 < (1ull << 32) &&
                       (uint64_t)Nq * (uint64_t)q_sn * 2 < (1ull << 32);
-  if (unit && Nk > 512 && span32 && !(pe2 && pe2[0] == '0') && prio == 0 && var == 1)
+  if (unit && Nk > 512 && span32 && !(pe2 && pe2[0] == '0') && prio == 0 && var == 1) {
+    g_last_attn_kernel = "attn_fwd_pipe_kernel";
     return attn_fwd_pipe_launch(q, k, v, o, lse, B, H, Nq, Nk, q_sb, q_sn, q_sh, k_sb, k_sn, k_sh, v_sb, v_sn, v_sh, o_sb, o_sn,
                                 o_sh, scale, !(xe && xe[0] == '0'), (hipStream_t)stream);
-  if (Nk <= 512) rc = launch(attn_fwd_kernel<NW, 0, true, 0>);
-  else if (prio == 1) rc = launch(attn_fwd_kernel<NW, 1, false, 0>);
-  else if (var == 0) rc = launch(attn_fwd_kernel<NW, 0, false, 0>);
-  else if (unit) rc = launch(attn_fwd_kernel<NW, 0, false, 3>);
-  else rc = launch(attn_fwd_kernel<NW, 0, false, 1>);
+  }
+  if (Nk <= 512) { g_last_attn_kernel = "attn_fwd_kernel<8, 0, true, 0>"; rc = launch(attn_fwd_kernel<NW, 0, true, 0>); }
+  else if (prio == 1) { g_last_attn_kernel = "attn_fwd_kernel<8, 1, false, 0>"; rc = launch(attn_fwd_kernel<NW, 1, false, 0>); }
+  else if (var == 0) { g_last_attn_kernel = "attn_fwd_kernel<8, 0, false, 0>"; rc = launch(attn_fwd_kernel<NW, 0, false, 0>); }
+  else if (unit) { g_last_attn_kernel = "attn_fwd_kernel<8, 0, false, 3>"; rc = launch(attn_fwd_kernel<NW, 0, false, 3>); }
+  else { g_last_attn_kernel = "attn_fwd_kernel<8, 0, false, 1>"; rc = launch(attn_fwd_kernel<NW, 0, false, 1>); }
   if (rc != LCV_OK) return rc;
   LCV_LAUNCH_CHECK("attn_fwd");
   return LCV_OK;

@@ -94,6 +94,8 @@ def load():
     lib.lcv_version.argtypes = []
     lib.lcv_last_error.restype = c_char_p
     lib.lcv_last_error.argtypes = []
+    lib.lcv_attn_fwd_last_kernel.restype = c_char_p
+    lib.lcv_attn_fwd_last_kernel.argtypes = []
     for name, args in _SIGNATURES.items():
         fn = getattr(lib, name, None)
         if fn is None:

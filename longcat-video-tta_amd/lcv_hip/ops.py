@@ -149,7 +149,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float,
          float(scale), _stream())
     if PROFILE is not None:
         ev1.record()
-        PROFILE.append((ev0, ev1, 4.0 * B * H * Nq * Nk * D, Nq, Nk))
+        PROFILE.append((ev0, ev1, 4.0 * B * H * Nq * Nk * D, Nq, Nk, _lib.load().lcv_attn_fwd_last_kernel().decode()))
     return out, lse
 
 

@@ -85,13 +85,22 @@ class LongCatVideoTransformer3DModel(nn.Module):
         known = set(_DEFAULT_CONFIG)
         model = cls(device=device or "cpu", dtype=torch_dtype, **{k: v for k, v in cfg.items() if k in known})
         from safetensors.torch import load_file
-        shards = sorted(f for f in os.listdir(path) if f.endswith(".safetensors"))
+        # diffusers layout: one `diffusion_pytorch_model.safetensors`, or shards listed by `*.safetensors.index.json`
+        index = [f for f in os.listdir(path) if f.endswith(".safetensors.index.json")]
+        if index:
+            with open(os.path.join(path, index[0])) as f:
+                shards = sorted(set(json.load(f)["weight_map"].values()))
+            absent = [s for s in shards if not os.path.exists(os.path.join(path, s))]
+            if absent:
+                raise FileNotFoundError(f"{index[0]} names shards that are not under {path}: {absent}")
+        else:
+            shards = sorted(f for f in os.listdir(path) if f.endswith(".safetensors"))
         if not shards:
             raise FileNotFoundError(f"no .safetensors weights under {path}")
         state = {}
         for s in shards:
             state.update(load_file(os.path.join(path, s)))
-        missing, unexpected = model.load_state_dict(state, strict=False)
+        missing, unexpected = model.load_state_dict(state, strict=False)     # (copy_ casts fp32 shards to torch_dtype)
         if missing:
             raise RuntimeError(f"checkpoint is missing {len(missing)} tensors, e.g. {missing[:5]}")
         return model
