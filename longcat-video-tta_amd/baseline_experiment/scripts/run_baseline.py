@@ -68,7 +68,7 @@ def main(argv=None):
         e = entries[idx]
         try:
             blob = R.load_entry(e, args, dit, device, total_frames=args.num_cond_frames)
-            out, dt = R.generate_continuation(pipe, blob, args, idx, device, num_frames=num_frames)
+            out, dt = R.generate_continuation(pipe, blob, args, idx, device, num_frames=num_frames, entry=e)
             row = {"idx": idx, "index": idx, "filename": e["name"], "caption": blob.get("caption", ""), "psnr": None,
                    "ssim": None, "lpips": None, "resolution": args.resolution, "inference_time_s": round(dt, 2)}
             if pipe.vae is not None:

@@ -67,7 +67,13 @@ LCV_EPI_NONE, LCV_EPI_SWIGLU, LCV_EPI_GATE_RESIDUAL, LCV_EPI_GELU_TANH, LCV_EPI_
 
 
 class LcvError(RuntimeError):
-    pass
+    """`code` is the library's return value when the error came from a C-ABI call (LCV_EINVAL -1: the caller's arguments;
+    LCV_EDEVICE -2 / LCV_ELAUNCH -3: the device or a launch failed — the HIP context may be unusable afterwards)."""
+    code = None
+
+    @property
+    def fatal(self) -> bool:
+        return self.code in (-2, -3)
 
 
 _lib = None
@@ -112,4 +118,6 @@ def call(name: str, *args):
     rc = fn(*args)
     if rc != 0:
         msg = lib.lcv_last_error()
-        raise LcvError(f"{name} failed ({rc}): {msg.decode() if msg else ''}")
+        err = LcvError(f"{name} failed ({rc}): {msg.decode() if msg else ''}")
+        err.code = rc
+        raise err

@@ -163,7 +163,10 @@ def _ensure_gemm_workspace(device: torch.device) -> None:
     idx = device.index if device.index is not None else torch.cuda.current_device()
     if idx not in _GEMM_WS:
         if _GEMM_WS:                       # a second device in the same process: the library holds ONE workspace
-            return
+            raise _lib.LcvError(
+                f"gemm_nt on cuda:{idx}, but this process already bound the library's split-K workspace to cuda:"
+                f"{next(iter(_GEMM_WS))}: the build runs one process per GPU (torch.distributed), a second device in the "
+                "same process would write its partial sums into the first device's memory")
         ws = torch.empty(GEMM_WS_BYTES, dtype=torch.uint8, device=device)
         call("lcv_gemm_set_workspace", _ptr(ws), GEMM_WS_BYTES)
         _GEMM_WS[idx] = ws

@@ -35,11 +35,30 @@ def merge_results(per_rank: Sequence[Sequence[Dict[str, Any]]]) -> List[Dict[str
     return rows
 
 
+_HOST_GROUP = None
+
+
+def host_group():
+    """A gloo (host-side) process group with a day-long timeout for the end-of-job result merge.  Ranks finish their video
+    shards at very different times (early stopping, skipped videos): a rank parked in an RCCL collective while the others
+    still work trips the collective watchdog and aborts the job before `summary.json` exists; a host-side gather just waits.
+    Collective: every rank must call it once, at start-up (tta/runner_common.setup_distributed does)."""
+    global _HOST_GROUP
+    import datetime
+    import torch.distributed as dist
+    if _HOST_GROUP is None and dist.is_initialized() and dist.get_world_size() > 1:
+        _HOST_GROUP = dist.new_group(backend="gloo", timeout=datetime.timedelta(hours=24))
+    return _HOST_GROUP
+
+
 def gather_results(local_rows: List[Dict[str, Any]], group=None) -> Optional[List[Dict[str, Any]]]:
-    """All ranks call; rank 0 gets the merged list (one `gather_object`, the only collective of the DP path)."""
+    """All ranks call; rank 0 gets the merged list (one `gather_object` over the HOST group: the only collective of the DP
+    path, and never on the device's collective queue)."""
     import torch.distributed as dist
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return merge_results([local_rows])
+    if group is None:
+        group = host_group()
     world = dist.get_world_size(group)
     out = [None] * world if dist.get_rank(group) == 0 else None
     dist.gather_object(local_rows, out, dst=0, group=group)

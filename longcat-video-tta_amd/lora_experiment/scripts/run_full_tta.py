@@ -120,7 +120,7 @@ def main(argv=None):
                       "batch_size": 1, "num_neighbors": 0, "early_stopping_info": tr.get("early_stopping_info"), "success": True}
             gen_time = 0.0
             if not args.skip_generation:
-                out, gen_time = R.generate_continuation(pipe, blob, args, idx, device)
+                out, gen_time = R.generate_continuation(pipe, blob, args, idx, device, entry=e)
                 if pipe.vae is not None:
                     t1 = time.time()
                     frames = pipe.decode_to_frames(out)
@@ -139,6 +139,9 @@ def main(argv=None):
             print(f"  ERROR: {ex}")
             traceback.print_exc()
             all_results.append({"idx": idx, "video_name": e["name"], "video_path": e["path"], "error": str(ex), "success": False})
+            if getattr(ex, "fatal", False):   # a failed launch / device error: the HIP context may be dead — stop here
+                dp.write_checkpoint(args.output_dir, idx, all_results, rank=rank if world > 1 else None)
+                raise
         dp.write_checkpoint(args.output_dir, idx + world, all_results, rank=rank if world > 1 else None)
 
     merged = dp.gather_results(all_results) if world > 1 else dp.merge_results([all_results])

@@ -104,6 +104,7 @@ def main(argv=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl")
+        dp.host_group()          # the gloo group of the end-of-job merge is created while every rank is still here
     device = f"cuda:{local_rank}" if args.device.startswith("cuda") else args.device
     torch.manual_seed(args.seed)
     np.random.seed(args.seed)
@@ -195,18 +196,10 @@ def main(argv=None):
                       "success": True}
             gen_time = 0.0
             if not args.skip_generation:
-                t0 = time.time()
-                n_valid = num_frames_valid(args.num_frames)
-                T_lat = _estimate_latent_len(n_valid)
-                ncl = _estimate_latent_len(args.num_cond_frames)
-                g = torch.Generator(device=device).manual_seed(args.seed + idx)
-                lat = torch.randn((1,) + tuple(blob["latents"].shape[1:2]) + (T_lat,) + tuple(blob["latents"].shape[3:]),
-                                  generator=g, device=device, dtype=torch.float32)
-                lat[:, :, :ncl] = blob["latents"][:, :, -ncl:].float()
-                out = pipe.denoise(lat, blob["prompt_embeds"], blob["prompt_mask"], blob.get("negative_embeds"),
-                                   blob.get("negative_mask"), num_cond_latents=ncl,
-                                   num_inference_steps=args.num_inference_steps, guidance_scale=args.guidance_scale,
-                                   use_kv_cache=True)
+                from tta.runner_common import generate_continuation
+                out, gen_only = generate_continuation(pipe, blob, args, idx, device, entry=e)   # cond encode + denoise
+                result["cond_source"] = blob.get("_cond_source")
+                t0 = time.time() - gen_only
                 frames = pipe.decode_to_frames(out) if pipe.vae is not None else None
                 torch.cuda.synchronize()
                 gen_time = time.time() - t0
@@ -228,6 +221,9 @@ def main(argv=None):
             traceback.print_exc()
             all_results.append({"idx": idx, "video_name": e["name"], "video_path": e["path"], "error": str(ex),
                                 "success": False})
+            if getattr(ex, "fatal", False):   # a failed launch / device error: the HIP context may be dead — stop here
+                dp.write_checkpoint(args.output_dir, idx, all_results, rank=rank if world > 1 else None)
+                raise
         dp.write_checkpoint(args.output_dir, idx + world, all_results, rank=rank if world > 1 else None)
 
     merged = dp.gather_results(all_results) if world > 1 else dp.merge_results([all_results])

@@ -55,6 +55,7 @@ def setup_distributed(args):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl")
+        dp.host_group()          # the gloo group of the end-of-job merge is created while every rank is still here
     device = f"cuda:{local_rank}" if args.device.startswith("cuda") else args.device
     return rank, world, device
 
@@ -122,22 +123,63 @@ def load_entry(entry, args, dit, device, total_frames=None):
     if entry["kind"] == "latents":
         blob = torch.load(entry["path"], map_location=device)
         blob.setdefault("caption", "")
+        blob["latents"] = blob["latents"].to(torch.bfloat16)     # the TTA loss works on bf16 latents (common.py:463-466)
         return blob
     raise NotImplementedError("raw-video input needs the PyAV decode + UMT5 rows that precede the hot path "
                               "(SURVEY §8(f)); pre-encode to <data-dir>/latents/*.pt")
 
 
-def generate_continuation(pipe, blob, args, idx, device, num_frames=None):
-    """KV-cached CFG continuation from the clean conditioning latents (what `generate_video_continuation`,
-    common.py:566-611, does after its VAE encode).  Returns (denoised latents, seconds)."""
+def continuation_cond_latents(pipe, blob, entry, args, device):
+    """Clean conditioning latents of the continuation, the way the reference obtains them: the `num_cond_frames` PIXEL frames
+    that end at `gen_start_frame` are VAE-encoded ON THEIR OWN (lora_experiment/scripts/run_lora_tta.py:1197-1217 ->
+    `generate_video_continuation` -> `pipe.generate_vc`, delta_experiment/scripts/common.py:566-611).  With a causal VAE that is
+    NOT a slice of the longer TTA-window encode: the standalone clip gets its own first-frame treatment and spans exactly
+    1 + 4k frames.  Sources, in order:
+      `cond_latents`  normalised latents of that standalone encode, prepared with the entry;
+      `cond_frames`   uint8 [n, H, W, 3] (or float [-1, 1] [1, 3, n, H, W]) pixels of those frames: encoded here with the HIP
+                      encoder (posterior mode, normalised), the last 1 + 4k of them;
+      synthetic entry seeded random pixels through the same encode (plumbing: the path is the real one);
+      otherwise       the last latents of the TTA window — a DECLARED deviation (`cond_source = "sliced_tta_window"`): such an
+                      entry's PSNR / SSIM are not comparable with the reference's tables.
+    Returns (latents fp32 [1, C, n_lat, h, w], source)."""
+    ncl = _estimate_latent_len(args.num_cond_frames)
+    if blob.get("cond_latents") is not None:
+        z = blob["cond_latents"].to(device).float()
+        return z[:, :, -ncl:], "cond_latents"
+    frames = blob.get("cond_frames")
+    source = "cond_frames"
+    if frames is None and entry is not None and entry.get("kind") == "synthetic" and pipe.vae is not None:
+        H, W = {"480p": (480, 832), "720p": (720, 1280)}[args.resolution]
+        g = torch.Generator(device=device).manual_seed(entry["seed"] + 104729)
+        frames = torch.randint(0, 256, (args.num_cond_frames, H, W, 3), generator=g, device=device, dtype=torch.uint8)
+        source = "synthetic_cond_frames"
+    if frames is not None and pipe.vae is not None:
+        f = torch.as_tensor(frames).to(device)
+        if f.dtype == torch.uint8:
+            f = (f.float() / 255.0 * 2.0 - 1.0).permute(3, 0, 1, 2).unsqueeze(0)          # [1, 3, n, H, W] in [-1, 1]
+        n = f.shape[2]
+        keep = 1 + 4 * ((n - 1) // 4)                                                     # the encoder takes 1 + 4k frames
+        dist = pipe.vae.encode(f[:, :, n - keep:].to(pipe.vae.dtype)).latent_dist
+        mean = torch.tensor(pipe.vae.config.latents_mean, device=device, dtype=torch.float32).view(1, -1, 1, 1, 1)
+        std = torch.tensor(pipe.vae.config.latents_std, device=device, dtype=torch.float32).view(1, -1, 1, 1, 1)
+        return (dist.mode().float() - mean) / std, source
+    return blob["latents"][:, :, -ncl:].float(), "sliced_tta_window"
+
+
+def generate_continuation(pipe, blob, args, idx, device, num_frames=None, entry=None):
+    """KV-cached CFG continuation from the clean conditioning latents (`generate_video_continuation`, common.py:566-611).
+    The conditioning encode is inside the timed region, as in the reference.  Returns (denoised latents, seconds); the
+    origin of the conditioning latents is left in `blob["_cond_source"]` for the per-video result."""
+    torch.cuda.synchronize()
     t0 = time.time()
     n_valid = num_frames_valid(num_frames if num_frames is not None else args.num_frames)
     T_lat = _estimate_latent_len(n_valid)
-    ncl = _estimate_latent_len(args.num_cond_frames)
+    cond, source = continuation_cond_latents(pipe, blob, entry, args, device)
+    blob["_cond_source"] = source
+    ncl = cond.shape[2]
     g = torch.Generator(device=device).manual_seed(args.seed + idx)
-    lat0 = blob["latents"]
-    lat = torch.randn((1, lat0.shape[1], T_lat) + tuple(lat0.shape[3:]), generator=g, device=device, dtype=torch.float32)
-    lat[:, :, :ncl] = lat0[:, :, -ncl:].float()
+    lat = torch.randn((1, cond.shape[1], T_lat) + tuple(cond.shape[3:]), generator=g, device=device, dtype=torch.float32)
+    lat[:, :, :ncl] = cond
     out = pipe.denoise(lat, blob["prompt_embeds"], blob["prompt_mask"], blob.get("negative_embeds"), blob.get("negative_mask"),
                        num_cond_latents=ncl, num_inference_steps=args.num_inference_steps,
                        guidance_scale=args.guidance_scale, use_kv_cache=True)
@@ -241,7 +283,7 @@ def run_delta_method(args, method: str, make_wrapper: Callable, optimize_fn: Cal
             if not args.skip_generation:
                 wrapper.apply_to_dit()
                 try:
-                    out, gen_time = generate_continuation(pipe, blob, args, idx, device)
+                    out, gen_time = generate_continuation(pipe, blob, args, idx, device, entry=e)
                 finally:
                     wrapper.remove_from_dit()
                 if pipe.vae is not None:
@@ -264,6 +306,9 @@ def run_delta_method(args, method: str, make_wrapper: Callable, optimize_fn: Cal
             traceback.print_exc()
             all_results.append({"idx": idx, "video_name": e["name"], "video_path": e["path"], "error": str(ex),
                                 "success": False})
+            if getattr(ex, "fatal", False):   # a failed launch / device error: the HIP context may be dead — stop here
+                dp.write_checkpoint(args.output_dir, idx, all_results, rank=rank if world > 1 else None)
+                raise
         finally:
             if cleanup is not None and wrapper is not None:
                 cleanup(wrapper)   # e.g. norm tuning: put the job's original weights back before the next video
