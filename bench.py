@@ -232,6 +232,9 @@ def measure_extras(dit, dev, T, h, w, pe, pm) -> dict:
     torch.cuda.synchronize(); t0 = time.perf_counter()
     vae.decode(z)
     torch.cuda.synchronize(); out["vae_decode_s"] = time.perf_counter() - t0
+    work = vae.decode_work(T, h, w)              # algorithmic conv / attention MACs of the decoder graph (true channel counts)
+    out["vae_decode_tflop"] = round(work["flops"] / 1e12, 1)
+    out["vae_decode_frac_of_mfma_peak"] = round(work["flops"] / out["vae_decode_s"] / 1e12 / MFMA_PEAK_TFLOPS, 3)
     del vae, z
     for b in dit.blocks:          # the fused SwiGLU weight copies are inference-only: give their 9 GB to the activations
         b.ffn._w13 = None

@@ -4,33 +4,48 @@
 #include "lcv_common.h"
 
 // y[c] = x[c] / max(||x||_2, 1e-12) * sqrt(C) * gamma[c]  (then SiLU); channels >= C (padding) are written as 0.
-// One wave per pixel row; Cpad <= 512.
+// HBM-bound: 4 B per element (bf16 in, bf16 out).  A pixel row of Cpad channels is Cpad / 8 sixteen-byte pieces; LPR lanes
+// (the next power of two: 16 at the 128-channel top level, 32 at 256, 64 at 384 / 512) share one row, so a wave covers
+// 64 / LPR consecutive rows and EVERY lane moves 16 bytes per instruction (the first form gave a whole wave to each row: at
+// 128 channels 48 of 64 lanes idled and the 49x720p top level ran at 0.17 of the HBM peak).  Workgroups walk the rows with a
+// grid stride, two row groups in flight per wave.
+template <int LPR>
 __global__ __launch_bounds__(256) void vae_rmsnorm_kernel(const bf16_t* __restrict__ x,
                                                           const bf16_t* __restrict__ gamma,
                                                           bf16_t* __restrict__ y, int64_t rows, int C, int Cpad,
                                                           int apply_silu) {
+  constexpr int RPW = 64 / LPR;                       // rows per wave
   const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const int c = lane * 8;
-  float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (c < Cpad) unpack8(*reinterpret_cast<const u16x8*>(x + row * Cpad + c), v);
-  float ss = 0.f;
+  const int sub = lane / LPR;                         // which of the wave's rows
+  const int c = (lane % LPR) * 8;
+  const bool live = c < Cpad;
+  float g[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (live) unpack8(*reinterpret_cast<const u16x8*>(gamma + c), g);  // gamma is stored padded to Cpad
+  const float sqrt_c = sqrtf((float)C);
+  const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t n_waves = (int64_t)gridDim.x * 4;
+  for (int64_t r0 = wave_id * RPW; r0 < rows; r0 += n_waves * RPW) {
+    const int64_t row = r0 + sub;
+    const bool ok = live && row < rows;
+    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (ok) unpack8(*reinterpret_cast<const u16x8*>(x + row * Cpad + c), v);
+    float ss = 0.f;
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
-    if (c + i < C) ss += v[i] * v[i];
-  ss = wave_sum(ss);
-  const float inv = sqrtf((float)C) / fmaxf(sqrtf(ss), 1e-12f);
-  if (c < Cpad) {
-    float g[8], o[8];
-    unpack8(*reinterpret_cast<const u16x8*>(gamma + c), g);  // gamma is stored padded to Cpad
+    for (int i = 0; i < 8; ++i)
+      if (c + i < C) ss += v[i] * v[i];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      float t = (c + i < C) ? v[i] * inv * g[i] : 0.f;
-      if (apply_silu) t = silu_f(t);
-      o[i] = t;
+    for (int o = LPR / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);   // stays inside the row's LPR lanes
+    const float inv = sqrt_c / fmaxf(sqrtf(ss), 1e-12f);
+    if (ok) {
+      float o8[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float t = (c + i < C) ? v[i] * inv * g[i] : 0.f;
+        if (apply_silu) t = silu_f(t);
+        o8[i] = t;
+      }
+      *reinterpret_cast<u16x8*>(y + row * Cpad + c) = pack8(o8);
     }
-    *reinterpret_cast<u16x8*>(y + row * Cpad + c) = pack8(o);
   }
 }
 
@@ -39,8 +54,18 @@ extern "C" int lcv_vae_rmsnorm_silu(const void* x, const void* gamma, void* y, i
   LCV_CHECK_ARG(x && gamma && y, "vae_rmsnorm_silu: null pointer");
   LCV_CHECK_ARG(Cpad % 8 == 0 && Cpad <= 512 && C <= Cpad && C > 0, "vae_rmsnorm_silu: C=%ld Cpad=%ld unsupported", (long)C, (long)Cpad);
   if (rows == 0) return LCV_OK;
-  hipLaunchKernelGGL(vae_rmsnorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)x, (const bf16_t*)gamma, (bf16_t*)y, rows, (int)C, (int)Cpad, apply_silu);
+  const int lpr = Cpad <= 128 ? 16 : (Cpad <= 256 ? 32 : 64);
+  const int64_t rows_per_block = 4 * (64 / lpr);
+  int64_t blocks = (rows + rows_per_block - 1) / rows_per_block;
+  if (blocks > 256 * 32) blocks = 256 * 32;          // grid stride beyond 32 workgroups per CU
+  const dim3 grid((unsigned)blocks), blk(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (lpr == 16)
+    hipLaunchKernelGGL(vae_rmsnorm_kernel<16>, grid, blk, 0, st, (const bf16_t*)x, (const bf16_t*)gamma, (bf16_t*)y, rows, (int)C, (int)Cpad, apply_silu);
+  else if (lpr == 32)
+    hipLaunchKernelGGL(vae_rmsnorm_kernel<32>, grid, blk, 0, st, (const bf16_t*)x, (const bf16_t*)gamma, (bf16_t*)y, rows, (int)C, (int)Cpad, apply_silu);
+  else
+    hipLaunchKernelGGL(vae_rmsnorm_kernel<64>, grid, blk, 0, st, (const bf16_t*)x, (const bf16_t*)gamma, (bf16_t*)y, rows, (int)C, (int)Cpad, apply_silu);
   LCV_LAUNCH_CHECK("vae_rmsnorm_silu");
   return LCV_OK;
 }

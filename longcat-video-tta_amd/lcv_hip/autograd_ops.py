@@ -349,8 +349,8 @@ class _SPSelfAttentionFn(torch.autograd.Function):
         do = do.contiguous()
         q = qk[:, :, 0]
         dq = torch.zeros((B, N, H, D), dtype=BF16, device=qkv.device)
-        dk_full = torch.zeros_like(k_full)
-        dv_full = torch.zeros_like(v_full)
+        dk_full = sp.padded_zeros(k_full)       # allocated in the reduce-scatter's layout (pads at the end)
+        dv_full = sp.padded_zeros(v_full)
         i = 0
         if n_cond_loc > 0:
             ops.attention_bwd(q[:, :n_cond_loc], k_full[:, :n_cond_glob], v_full[:, :n_cond_glob], o[:, :n_cond_loc],
@@ -380,6 +380,8 @@ def sp_self_attention(qkv, wq, wk, cs, scale, eps, sp, n_cond_loc, n_cond_glob):
     B, N, _, H, D = qkv.shape
     q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
     ops.qknorm_rope(q, k, None, q, k, None, wq, wk, cs, sp.token_offset, eps, q_scale=ops.log2_qscale(scale))
+    if n_cond_glob == 0 and sp.overlap and qkv.is_cuda and sp.world > 1:
+        return _sp_attention_overlapped(q, k.contiguous(), v.contiguous(), sp)
     k_full, v_full = sp.all_gather_kv(k.contiguous(), v.contiguous())
     if n_cond_glob == 0:
         o, _ = ops.attention(q, k_full, v_full, ops.LN2)
@@ -390,6 +392,35 @@ def sp_self_attention(qkv, wq, wk, cs, scale, eps, sp, n_cond_loc, n_cond_glob):
     if N > n_cond_loc:
         ops.attention(q[:, n_cond_loc:], k_full, v_full, ops.LN2, out=o[:, n_cond_loc:])
     return o
+
+
+def _sp_attention_overlapped(q, k_loc, v_loc, sp):
+    """LCV_SP_OVERLAP=1 (inference, no conditioning split): the K/V all-gather runs on a side stream while the flash kernel
+    attends the LOCAL keys; the keys of the ranks before and after follow once the gather has landed, and the partial
+    results are merged through their log-sum-exps:  o = sum_i o_i * exp(lse_i - lse),  lse = logsumexp_i(lse_i).
+    Same softmax, partitioned over key ranges: equal to the one-call form up to rounding, NOT bit-identical."""
+    main = torch.cuda.current_stream()
+    side = sp.side_stream(q.device)
+    side.wait_stream(main)                                   # K / V of this layer are final on the main stream
+    with torch.cuda.stream(side):
+        k_full, v_full = sp.all_gather_kv(k_loc, v_loc)
+    parts = [ops.attention(q, k_loc, v_loc, ops.LN2, need_lse=True)]          # overlaps the collective
+    main.wait_stream(side)
+    k_full.record_stream(main); v_full.record_stream(main)
+    lo, hi = sp.token_offset, sp.token_offset + k_loc.shape[1]
+    if lo > 0:
+        parts.append(ops.attention(q, k_full[:, :lo], v_full[:, :lo], ops.LN2, need_lse=True))
+    if hi < k_full.shape[1]:
+        parts.append(ops.attention(q, k_full[:, hi:], v_full[:, hi:], ops.LN2, need_lse=True))
+    if len(parts) == 1:
+        return parts[0][0]
+    lses = torch.stack([l for _, l in parts], 0)                               # [P, B, H, N] natural-log units
+    lse = torch.logsumexp(lses, dim=0)
+    out = None
+    for (o_i, l_i) in parts:
+        w_i = torch.exp(l_i - lse).permute(0, 2, 1).unsqueeze(-1)              # [B, N, H, 1]
+        out = o_i.float() * w_i if out is None else out + o_i.float() * w_i
+    return out.to(BF16)
 
 
 def cached_attention(qkv, k_c, v_c, wq, wk, cs, scale, eps):

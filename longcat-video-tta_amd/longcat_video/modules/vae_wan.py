@@ -72,9 +72,13 @@ class _Norm(nn.Module):
         self.gamma = nn.Parameter(torch.ones(shape, device=device, dtype=dtype), requires_grad=False)
 
     def padded(self) -> torch.Tensor:
-        g = torch.zeros(_pad64(self.dim), dtype=BF16, device=self.gamma.device)
-        g[: self.dim] = self.gamma.detach().flatten().to(BF16)
-        return g
+        """gamma zero-padded to the kernels' channel pitch; cached (two tiny launches per norm call otherwise)."""
+        key = (self.gamma._version, self.gamma.data_ptr())
+        if getattr(self, "_pad_key", None) != key:
+            g = torch.zeros(_pad64(self.dim), dtype=BF16, device=self.gamma.device)
+            g[: self.dim] = self.gamma.detach().flatten().to(BF16)
+            self._padded, self._pad_key = g, key
+        return self._padded
 
 
 class _Res(nn.Module):
@@ -357,6 +361,45 @@ class AutoencoderKLWan(nn.Module):
         if return_dict:
             return SimpleNamespace(latent_dist=dist)
         return (dist,)
+
+    def decode_work(self, T: int, h: int, w: int) -> dict:
+        """ALGORITHMIC work of `decode` on latents [1, z, T, h, w] (true channel counts, no padding): `flops` = 2 x MACs of every
+        convolution and of the mid-block attention; `norm_bytes` = 4 B per element through the channel RMS norms (bf16 in + out).
+        Walks the same graph as `decode` ("count from the restated decoder graph")."""
+        d = self.decoder
+        fl = nb = 0
+
+        def conv(c, t, hh, ww):
+            taps = 1
+            for k in c.k:
+                taps *= k
+            return 2 * t * hh * ww * c.cout * c.cin * taps
+
+        def res(r, t, hh, ww):
+            f = conv(r.conv1, t, hh, ww) + conv(r.conv2, t, hh, ww)
+            if not isinstance(r.conv_shortcut, nn.Identity):
+                f += conv(r.conv_shortcut, t, hh, ww)
+            return f, 4 * t * hh * ww * (r.conv1.cin + r.conv2.cin)
+
+        fl += conv(self.post_quant_conv, T, h, w) + conv(d.conv_in, T, h, w)
+        t, hh, ww = T, h, w
+        for r in d.mid_block.resnets:
+            f, b = res(r, t, hh, ww); fl += f; nb += b
+        a = d.mid_block.attentions[0]
+        n, C = hh * ww, a.proj.cin
+        fl += t * (2 * n * 3 * C * C + 4 * n * n * C + 2 * n * C * C); nb += 4 * t * n * C
+        for ub in d.up_blocks:
+            for r in ub.resnets:
+                f, b = res(r, t, hh, ww); fl += f; nb += b
+            if ub.upsamplers is not None:
+                u = ub.upsamplers[0]
+                if u.mode == "upsample3d" and t > 1:
+                    fl += conv(u.time_conv, t - 1, hh, ww)
+                    t = 1 + 2 * (t - 1)
+                hh, ww = 2 * hh, 2 * ww
+                fl += conv(u.resample[1], t, hh, ww)
+        fl += conv(d.conv_out, t, hh, ww); nb += 4 * t * hh * ww * d.conv_out.cin
+        return {"flops": fl, "norm_bytes": nb, "frames": t, "height": hh, "width": ww}
 
     @torch.no_grad()
     def decode(self, z: torch.Tensor, return_dict: bool = False):

@@ -3,37 +3,75 @@ every per-token op is local (the adaLN table is per frame, RoPE uses GLOBAL posi
 all-gathers K and V (post-norm, post-RoPE) so each rank runs local-Q x full-KV on the flash kernel.
 
 Collectives (torch.distributed; backend "nccl" = RCCL over xGMI on MI355X, "gloo" in the CPU tests):
-  forward   all_gather of K, V rows (uneven shards allowed: 31 frames over 8 ranks = 4,4,4,4,4,4,4,3)
-  backward  reduce_scatter of dK, dV (the adjoint of the all-gather)
-xGMI is point-to-point (7 links per GPU): RCCL's all-gather on a fully connected 8-GPU node is issued as direct peer
-exchanges, so a per-layer message of 2*N*C*2 bytes (792 MB at K5) moves over all 7 links, not around a ring.
+  forward   ONE `all_gather_into_tensor` per tensor straight into a [W * n_max, H, D] buffer: every rank but the last
+            holds ceil(T / W) frames, the last one the remainder (31 frames over 8 ranks = 4,4,4,4,4,4,4,3), so the pad
+            rows all sit at the END of the gathered buffer and the attention kernel simply sees its first N rows — no
+            list of W receive tensors, no `torch.cat` (1.6 GB of copies per layer at K5 in the first version);
+  backward  ONE `reduce_scatter_tensor` of the padded full-length dK / dV (the adjoint of the all-gather) — half the
+            bytes of the all-reduce + slice it replaces.
+When the remainder leaves the last rank empty (13 frames over 8 ranks) the shards fall back to "as even as possible"
+and the list / concatenate form, which is kept for that case only.
+No 8-GPU node was available to this build: the byte counts above are by construction, the overlap below is unmeasured.
+  optional  `LCV_SP_OVERLAP=1` (inference): the K/V gather runs on a side stream while the flash kernel attends the LOCAL
+            keys; the remote keys follow and the two partial results are merged through their log-sum-exps.  Not
+            bit-identical to the single-process forward (two softmax partitions), hence opt-in.
+xGMI is point-to-point (7 links per GPU); whether RCCL issues this all-gather as direct peer exchanges or as a ring on a
+fully connected node has not been verified here (a ring would be single-link bound: ~4.5 ms instead of ~0.65 ms per layer
+at K5).
 """
+import math
+import os
 from typing import List, Tuple
 
 import torch
 
 
 def frame_shards(num_frames: int, world_size: int) -> List[int]:
-    """Frames per rank, as even as possible, larger shards first (sum == num_frames)."""
+    """Frames per rank.  Preferred: ceil(T / W) on every rank and the remainder on the last (pads only at the end of the
+    gathered sequence); when that would leave a rank empty: as even as possible, larger shards first."""
+    per = math.ceil(num_frames / world_size)
+    counts = [min(per, max(0, num_frames - r * per)) for r in range(world_size)]
+    if counts[-1] > 0:
+        return counts
     base, rem = divmod(num_frames, world_size)
     return [base + (1 if r < rem else 0) for r in range(world_size)]
+
+
+def pads_at_end(counts: List[int]) -> bool:
+    """True when every rank but the last holds the same number of frames: the gathered, padded sequence is then
+    [valid tokens | pad], and one tensor collective serves."""
+    return len(counts) == 1 or (all(c == counts[0] for c in counts[:-1]) and 0 < counts[-1] <= counts[0])
 
 
 def token_offset(rank: int, counts: List[int], tokens_per_frame: int) -> int:
     return sum(counts[:rank]) * tokens_per_frame
 
 
-def _gather_rows(x: torch.Tensor, counts: List[int], S: int, group=None) -> torch.Tensor:
-    """All-gather along the token axis.  Shards may be uneven: each rank pads to the largest shard so the collective
-    is one equal-sized all_gather (what RCCL / gloo implement natively), then the pads are dropped."""
+def _pad_rows(x: torch.Tensor, n_max: int) -> torch.Tensor:
+    if x.shape[1] == n_max:
+        return x.contiguous()
+    out = x.new_zeros((x.shape[0], n_max) + tuple(x.shape[2:]))
+    out[:, : x.shape[1]].copy_(x)
+    return out
+
+
+def _gather_rows(x: torch.Tensor, counts: List[int], S: int, group=None, out: torch.Tensor = None) -> torch.Tensor:
+    """All-gather along the token axis; returns [B, N, ...] in frame order (a VIEW of the padded buffer when the pads sit
+    at the end, see `pads_at_end`)."""
     import torch.distributed as dist
     world = len(counts)
     n_max = max(counts) * S
-    if x.shape[1] < n_max:
-        pad = torch.zeros((x.shape[0], n_max - x.shape[1]) + tuple(x.shape[2:]), dtype=x.dtype, device=x.device)
-        x = torch.cat([x, pad], dim=1)
-    outs = [torch.empty_like(x) for _ in range(world)]
-    dist.all_gather(outs, x.contiguous(), group=group)
+    N = sum(counts) * S
+    B = x.shape[0]
+    xp = _pad_rows(x, n_max)
+    if pads_at_end(counts):
+        if out is None:
+            out = torch.empty((B, world * n_max) + tuple(x.shape[2:]), dtype=x.dtype, device=x.device)
+        for b in range(B):                                   # (B = 2 under CFG: two collectives, each into its own rows)
+            dist.all_gather_into_tensor(out[b], xp[b], group=group)
+        return out[:, :N]
+    outs = [torch.empty_like(xp) for _ in range(world)]      # gaps inside the sequence: gather, then drop the pads
+    dist.all_gather(outs, xp, group=group)
     return torch.cat([o[:, : c * S] for o, c in zip(outs, counts)], dim=1)
 
 
@@ -45,13 +83,25 @@ def all_gather_kv(k_local: torch.Tensor, v_local: torch.Tensor, counts: List[int
 
 
 def reduce_scatter_kv_grad(d_full: torch.Tensor, counts: List[int], tokens_per_frame: int, group=None) -> torch.Tensor:
-    """Sum the full-length dK (or dV) over ranks and keep this rank's rows."""
+    """Sum the full-length dK (or dV) [B, N, ...] over ranks and keep this rank's rows."""
     import torch.distributed as dist
     rank = dist.get_rank(group)
-    d = d_full.contiguous().clone()
-    dist.all_reduce(d, op=dist.ReduceOp.SUM, group=group)   # uneven shards: all-reduce + slice (reduce_scatter needs equal parts)
-    lo = sum(counts[:rank]) * tokens_per_frame
-    return d[:, lo:lo + counts[rank] * tokens_per_frame].contiguous()
+    world = len(counts)
+    S = tokens_per_frame
+    lo, n_loc = sum(counts[:rank]) * S, counts[rank] * S
+    if pads_at_end(counts):
+        n_max = max(counts) * S
+        B = d_full.shape[0]
+        base = getattr(d_full, "_lcv_padded", None)          # SPContext.padded_zeros: already the collective's layout
+        if base is None:
+            base = _pad_rows(d_full, world * n_max)
+        out = torch.empty((B, n_max) + tuple(d_full.shape[2:]), dtype=d_full.dtype, device=d_full.device)
+        for b in range(B):
+            dist.reduce_scatter_tensor(out[b], base[b], op=dist.ReduceOp.SUM, group=group)
+        return out[:, :n_loc].contiguous()
+    d = d_full.contiguous().clone()                          # gaps inside the sequence: all-reduce + slice
+    dist.all_reduce(d, op=dist.ReduceOp.SUM, group=group)
+    return d[:, lo:lo + n_loc].contiguous()
 
 
 class SPContext:
@@ -71,6 +121,17 @@ class SPContext:
         self.t1 = self.t0 + self.counts[self.rank]
         self.num_frames = num_frames
         self._host_staged = dist.get_backend(group) == "gloo"
+        self.overlap = os.environ.get("LCV_SP_OVERLAP", "0") == "1"
+
+    _SIDE = {}
+
+    def side_stream(self, device) -> "torch.cuda.Stream":
+        """One side stream per device for the K/V gather of the overlapped form.  It carries collectives only — no GEMM is
+        ever launched on it, so the library's single split-K workspace keeps having one user stream."""
+        key = str(device)
+        if key not in SPContext._SIDE:
+            SPContext._SIDE[key] = torch.cuda.Stream(device=device)
+        return SPContext._SIDE[key]
 
     @property
     def token_offset(self) -> int:
@@ -78,13 +139,30 @@ class SPContext:
 
     def _coll(self, fn, x: torch.Tensor) -> torch.Tensor:
         if self._host_staged and x.is_cuda:
-            return fn(x.cpu()).to(x.device)
+            base = getattr(x, "_lcv_padded", None)
+            xc = x.cpu()
+            if base is not None:
+                bc = base.cpu()
+                xc = bc[:, : x.shape[1]]
+                xc._lcv_padded = bc
+            return fn(xc).to(x.device)
         return fn(x)
 
     def all_gather_kv(self, k_local: torch.Tensor, v_local: torch.Tensor):
         k = self._coll(lambda t: _gather_rows(t, self.counts, self.S, self.group), k_local)
         v = self._coll(lambda t: _gather_rows(t, self.counts, self.S, self.group), v_local)
         return k, v
+
+    def padded_zeros(self, like: torch.Tensor) -> torch.Tensor:
+        """Zero gradient buffer for a gathered [B, N, H, D] tensor, allocated in the reduce-scatter's own layout
+        ([B, W * n_max, H, D], pads at the end) so that the collective needs no staging copy; returns the [B, N] view."""
+        if not pads_at_end(self.counts):
+            return torch.zeros_like(like)
+        n_max = max(self.counts) * self.S
+        base = torch.zeros((like.shape[0], self.world * n_max) + tuple(like.shape[2:]), dtype=like.dtype, device=like.device)
+        view = base[:, : like.shape[1]]
+        view._lcv_padded = base
+        return view
 
     def reduce_scatter_kv(self, d_full: torch.Tensor) -> torch.Tensor:
         """Adjoint of `all_gather_kv` for one tensor: sum the full-length gradient over ranks, keep this rank's rows."""

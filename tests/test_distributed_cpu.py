@@ -49,9 +49,33 @@ def _worker(rank, world, port, tmp):
         dk_full = torch.full((1, T * S, H, D), float(rank + 1))
         dk_local = sp.reduce_scatter_kv_grad(dk_full, counts, S)
         assert dk_local.shape[1] == counts[rank] * S and torch.all(dk_local == 3.0)
+        # the context object: gathered K/V are VIEWS of one padded buffer (pads at the end), the gradient buffer is allocated
+        # in the reduce-scatter's layout, CFG batch of two
+        ctx = sp.SPContext(T, S)
+        assert ctx.counts == [3, 2] and sp.pads_at_end(ctx.counts) and ctx.token_offset == lo
+        k2 = torch.stack([full_k[0], full_k[0] * 2.0])
+        kg, vg = ctx.all_gather_kv(k2[:, lo:hi].contiguous(), k2[:, lo:hi].contiguous())
+        assert torch.equal(kg, k2) and kg.shape == (2, T * S, H, D) and kg._base is not None and kg._base.shape[1] == 2 * 3 * S
+        dg = ctx.padded_zeros(kg)
+        assert dg.shape == kg.shape and dg._lcv_padded.shape[1] == 2 * 3 * S and not dg.any()
+        dg += float(rank + 1)
+        dl = ctx.reduce_scatter_kv(dg)
+        assert dl.shape == (2, counts[rank] * S, H, D) and torch.all(dl == 3.0)
         dist.barrier()
     finally:
         dist.destroy_process_group()
+
+
+def test_frame_shards_put_the_pads_at_the_end_when_they_can():
+    sys.path.insert(0, str(ROOT / "longcat-video-tta_amd"))
+    from longcat_video.parallel import sequence_parallel as sp
+    assert sp.frame_shards(31, 8) == [4, 4, 4, 4, 4, 4, 4, 3] and sp.pads_at_end(sp.frame_shards(31, 8))     # K5 on 8 GPUs
+    assert sp.frame_shards(32, 8) == [4] * 8 and sp.frame_shards(5, 2) == [3, 2] and sp.frame_shards(3, 2) == [2, 1]
+    assert sp.frame_shards(13, 8) == [2, 2, 2, 2, 2, 1, 1, 1] and not sp.pads_at_end(sp.frame_shards(13, 8))  # no empty rank
+    for T in range(1, 40):
+        for W in (1, 2, 3, 4, 8):
+            c = sp.frame_shards(T, W)
+            assert sum(c) == T and len(c) == W and all(x >= 0 for x in c) and c == sorted(c, reverse=True)
 
 
 def test_world_size_2_gloo():
