@@ -58,7 +58,10 @@ int lcv_adaln_modulate_bwd(const void* x, const float* mod, const void* dy,
                            void* dx, float* dmod,
                            int64_t B, int64_t T, int64_t S, int64_t C,
                            int64_t mod_stride, int64_t shift_off, int64_t scale_off,
-                           float eps, void* stream);
+                           float eps, const void* dres, void* stream);
+/* dres (nullable, bf16 [B,T*S,C]): a second gradient w.r.t. x — the one that arrives through the residual path of the same
+ * block — added to dx in fp32 before the one bf16 rounding.  It replaces the separate elementwise add autograd would launch
+ * for the fork x -> {norm, residual} (three per block and step in the TTA inner loop, run_lora_tta.py:512). */
 /* y = LN_fp32(x) * w + b  (affine LayerNorm_FP32; pre_crs_attn_norm).
  * Module name evidence: delta_experiment/scripts/run_norm_tune_tta.py:78-96. */
 int lcv_layernorm_affine_fwd(const void* x, const float* w, const float* b, void* y,
@@ -66,7 +69,7 @@ int lcv_layernorm_affine_fwd(const void* x, const float* w, const float* b, void
 /* dx (bf16) and, if non-NULL, dw/db fp32 [C] ACCUMULATED (atomics). */
 int lcv_layernorm_affine_bwd(const void* x, const float* w, const void* dy,
                              void* dx, float* dw, float* db,
-                             int64_t rows, int64_t C, float eps, void* stream);
+                             int64_t rows, int64_t C, float eps, const void* dres, void* stream);
 
 /* ---- gated residual ------------------------------------------------- */
 /* out = bf16( f32(x) + gate[b,t,:] * f32(y) ); gate addressed like shift above.

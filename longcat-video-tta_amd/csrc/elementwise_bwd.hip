@@ -21,7 +21,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void rownorm_bwd_kernel(
     const bf16_t* __restrict__ x, const float* __restrict__ p_mul, const bf16_t* __restrict__ dy,
     bf16_t* __restrict__ dx, float* __restrict__ d_add, float* __restrict__ d_mul, int64_t rows, int C,
-    int64_t S, int64_t mod_stride, float eps, int rows_per_block) {
+    int64_t S, int64_t mod_stride, float eps, int rows_per_block, const bf16_t* __restrict__ dres) {
   __shared__ float s_add[ROWNORM_MAXCH * 64 * 8], s_mul[ROWNORM_MAXCH * 64 * 8];
   const int lane = threadIdx.x & 63;
   const bool want_d = d_add != nullptr;
@@ -107,6 +107,12 @@ __global__ __launch_bounds__(256) void rownorm_bwd_kernel(
       float o[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) o[i] = rstd * (g[ch][i] - mg - v[ch][i] * mgx);
+      if (dres) {   // the gradient that reaches x through the residual path of the same block, summed here in fp32
+        float rr[8];
+        unpack8(*reinterpret_cast<const u16x8*>(dres + row * C + c), rr);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] += rr[i];
+      }
       *reinterpret_cast<u16x8*>(dr + c) = pack8(o);
     }
   }
@@ -122,7 +128,7 @@ __global__ __launch_bounds__(256) void rownorm_bwd_kernel(
 
 extern "C" int lcv_adaln_modulate_bwd(const void* x, const float* mod, const void* dy, void* dx, float* dmod,
                                       int64_t B, int64_t T, int64_t S, int64_t C, int64_t mod_stride,
-                                      int64_t shift_off, int64_t scale_off, float eps, void* stream) {
+                                      int64_t shift_off, int64_t scale_off, float eps, const void* dres, void* stream) {
   LCV_CHECK_ARG(x && mod && dy && dx, "adaln_modulate_bwd: null pointer");
   LCV_CHECK_ARG(C > 0 && C % 8 == 0 && C <= 4096, "adaln_modulate_bwd: C must be a multiple of 8 and <= 4096");
   const int64_t rows = B * T * S;
@@ -131,13 +137,13 @@ extern "C" int lcv_adaln_modulate_bwd(const void* x, const float* mod, const voi
   hipLaunchKernelGGL(rownorm_bwd_kernel<0>, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)x, mod + scale_off, (const bf16_t*)dy, (bf16_t*)dx,
                      dmod ? dmod + shift_off : nullptr, dmod ? dmod + scale_off : nullptr, rows, (int)C, S,
-                     mod_stride, eps, rpb);
+                     mod_stride, eps, rpb, (const bf16_t*)dres);
   LCV_LAUNCH_CHECK("adaln_modulate_bwd");
   return LCV_OK;
 }
 
 extern "C" int lcv_layernorm_affine_bwd(const void* x, const float* w, const void* dy, void* dx, float* dw,
-                                        float* db, int64_t rows, int64_t C, float eps, void* stream) {
+                                        float* db, int64_t rows, int64_t C, float eps, const void* dres, void* stream) {
   LCV_CHECK_ARG(x && w && dy && dx, "layernorm_affine_bwd: null pointer");
   LCV_CHECK_ARG((dw == nullptr) == (db == nullptr), "layernorm_affine_bwd: dw and db go together");
   LCV_CHECK_ARG(C > 0 && C % 8 == 0 && C <= 4096, "layernorm_affine_bwd: C must be a multiple of 8 and <= 4096");
@@ -145,7 +151,7 @@ extern "C" int lcv_layernorm_affine_bwd(const void* x, const float* w, const voi
   const int rpb = dw ? ROWNORM_RPB : 4;
   hipLaunchKernelGGL(rownorm_bwd_kernel<1>, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)x, w, (const bf16_t*)dy, (bf16_t*)dx, db, dw, rows, (int)C, (int64_t)1,
-                     (int64_t)0, eps, rpb);
+                     (int64_t)0, eps, rpb, (const bf16_t*)dres);
   LCV_LAUNCH_CHECK("layernorm_affine_bwd");
   return LCV_OK;
 }

@@ -165,6 +165,37 @@ class _AdaLNFn(torch.autograd.Function):
         return dx, dmod, None, None, None, None
 
 
+class _AdaLNForkFn(torch.autograd.Function):
+    """`(modulate(LN(x)), x)`: the norm at the entry of a residual branch together with the branch's residual input.  The
+    second output aliases x; in the backward the gradient that comes down the residual path is added to the norm's own dx
+    INSIDE the norm-backward kernel (one fp32 add before the single bf16 rounding) instead of by a separate elementwise
+    kernel of autograd's — three such forks per block and step."""
+
+    @staticmethod
+    def forward(ctx, x, mod, shift_idx, scale_idx, T, eps):
+        ctx.save_for_backward(x, mod)
+        ctx.args = (shift_idx, scale_idx, T, eps)
+        ctx.set_materialize_grads(False)
+        return ops.adaln_modulate(x, mod, shift_idx, scale_idx, T, eps), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dres):
+        x, mod = ctx.saved_tensors
+        shift_idx, scale_idx, T, eps = ctx.args
+        if dy is None:
+            return dres, None, None, None, None, None
+        dx, dmod = ops.adaln_modulate_bwd(x, mod, dy.contiguous(), shift_idx, scale_idx, T, eps,
+                                          need_dmod=ctx.needs_input_grad[1], dres=dres)
+        return dx, dmod, None, None, None, None
+
+
+def adaln_modulate_fork(x, mod, shift_idx, scale_idx, T, eps=1e-6):
+    """-> (x_modulated, x_residual).  Training form of `adaln_modulate` for a residual branch (see _AdaLNForkFn)."""
+    if _needs_grad(x, mod):
+        return _AdaLNForkFn.apply(x, mod, shift_idx, scale_idx, T, eps)
+    return ops.adaln_modulate(x, mod, shift_idx, scale_idx, T, eps), x
+
+
 def adaln_modulate(x, mod, shift_idx, scale_idx, T, eps=1e-6):
     if _needs_grad(x, mod):
         return _AdaLNFn.apply(x, mod, shift_idx, scale_idx, T, eps)
@@ -184,6 +215,32 @@ class _LayerNormAffineFn(torch.autograd.Function):
         dx, dw, db = ops.layernorm_affine_bwd(x, w, dy.contiguous(), ctx.eps,
                                               need_dw=ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
         return dx, (dw.to(w.dtype) if dw is not None else None), (db.to(w.dtype) if db is not None else None), None
+
+
+class _LayerNormAffineForkFn(torch.autograd.Function):
+    """`(LN(x) * w + b, x)` for the cross-attention branch: as _AdaLNForkFn."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        ctx.save_for_backward(x, w)
+        ctx.eps = eps
+        ctx.set_materialize_grads(False)
+        return ops.layernorm_affine(x, w, b, eps), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dres):
+        x, w = ctx.saved_tensors
+        if dy is None:
+            return dres, None, None, None
+        dx, dw, db = ops.layernorm_affine_bwd(x, w, dy.contiguous(), ctx.eps,
+                                              need_dw=ctx.needs_input_grad[1] or ctx.needs_input_grad[2], dres=dres)
+        return dx, (dw.to(w.dtype) if dw is not None else None), (db.to(w.dtype) if db is not None else None), None
+
+
+def layernorm_affine_fork(x, w, b, eps=1e-6):
+    if _needs_grad(x, w, b):
+        return _LayerNormAffineForkFn.apply(x, w, b, eps)
+    return ops.layernorm_affine(x, w, b, eps), x
 
 
 def layernorm_affine(x, w, b, eps=1e-6):

@@ -16,9 +16,9 @@ P, I64, F32, I, F64 = c_void_p, c_int64, c_float, c_int, c_double
 _SIGNATURES = {
     "lcv_device_check": [],
     "lcv_adaln_modulate_fwd": [P, P, P, I64, I64, I64, I64, I64, I64, I64, F32, P],
-    "lcv_adaln_modulate_bwd": [P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, F32, P],
+    "lcv_adaln_modulate_bwd": [P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, F32, P, P],
     "lcv_layernorm_affine_fwd": [P, P, P, P, I64, I64, F32, P],
-    "lcv_layernorm_affine_bwd": [P, P, P, P, P, P, I64, I64, F32, P],
+    "lcv_layernorm_affine_bwd": [P, P, P, P, P, P, I64, I64, F32, P, P],
     "lcv_gate_residual_fwd": [P, P, P, P, I64, I64, I64, I64, I64, I64, P],
     "lcv_gate_residual_bwd": [P, P, P, P, P, I64, I64, I64, I64, I64, I64, P],
     "lcv_qknorm_rope_fwd": [P, P, P, P, P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, I64, F32, F32, P],

@@ -317,26 +317,38 @@ def fm_mse_samples(pred: torch.Tensor, eps: torch.Tensor, x0: torch.Tensor, Tc: 
 
 
 # ===================================================================== backward kernels
-def adaln_modulate_bwd(x, mod, dy, shift_idx, scale_idx, T, eps=1e-6, need_dmod=False):
+def _res_grad(dres, like, name):
+    """Optional second gradient w.r.t. the norm's input (the residual path of the same block), added inside the kernel."""
+    if dres is None:
+        return None
+    _req(dres, BF16, name)
+    if tuple(dres.shape) != tuple(like.shape):
+        raise _lib.LcvError(f"{name}: shape {tuple(dres.shape)} does not match x {tuple(like.shape)}")
+    return dres.contiguous()
+
+
+def adaln_modulate_bwd(x, mod, dy, shift_idx, scale_idx, T, eps=1e-6, need_dmod=False, dres=None):
     _req(dy, BF16, "adaln_modulate_bwd.dy")
     B, N, C = x.shape
     dx = torch.empty_like(x)
     dmod = torch.zeros_like(mod) if need_dmod else None
+    dres = _res_grad(dres, x, "adaln_modulate_bwd.dres")
     call("lcv_adaln_modulate_bwd", _ptr(x), _ptr(mod), _ptr(dy), _ptr(dx), _ptr(dmod), B, T, N // T, C,
-         mod.shape[-1], shift_idx * C, scale_idx * C, eps, _stream())
+         mod.shape[-1], shift_idx * C, scale_idx * C, eps, _ptr(dres), _stream())
     return dx, dmod
 
 
-def layernorm_affine_bwd(x, w, dy, eps=1e-6, need_dw=False):
+def layernorm_affine_bwd(x, w, dy, eps=1e-6, need_dw=False, dres=None):
     _req(dy, BF16, "layernorm_affine_bwd.dy")
     C = x.shape[-1]
     x = x.contiguous()
+    dres = _res_grad(dres, x, "layernorm_affine_bwd.dres")
     wf = w.detach().to(F32).contiguous()
     dx = torch.empty_like(x)
     dw = torch.zeros(C, dtype=F32, device=x.device) if need_dw else None
     db = torch.zeros(C, dtype=F32, device=x.device) if need_dw else None
     call("lcv_layernorm_affine_bwd", _ptr(x), _ptr(wf), _ptr(dy), _ptr(dx), _ptr(dw), _ptr(db), x.numel() // C, C,
-         eps, _stream())
+         eps, _ptr(dres), _stream())
     return dx, dw, db
 
 

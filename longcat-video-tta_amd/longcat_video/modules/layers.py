@@ -362,7 +362,9 @@ class LongCatSingleStreamBlock(nn.Module):
         """x [B,N,C]; y [1, sum(y_seqlen), C]; t [B,T,C_t] fp32 (3rd positional arg: run_delta_b.py:188-191)."""
         T = latent_shape[0]
         mod = self.adaLN_modulation(t)  # [B, T, 6C] fp32: shift_msa|scale_msa|gate_msa|shift_mlp|scale_mlp|gate_mlp
-        x_m = A.adaln_modulate(x, mod, 0, 1, T, self.mod_norm_attn.eps)
+        # (x_m, x): under autograd the norm and the residual input leave ONE graph node, whose backward adds the residual
+        # path's gradient inside the norm-backward kernel (lcv_hip/autograd_ops.py::_AdaLNForkFn)
+        x_m, x = A.adaln_modulate_fork(x, mod, 0, 1, T, self.mod_norm_attn.eps)
         kv = None
         # residual + gate folded into the output projection's GEMM epilogue: inference only, and only while the module
         # whose forward receives the extra argument and the projection it swallows are pristine (hooks / LoRA keep working)
@@ -382,9 +384,14 @@ class LongCatSingleStreamBlock(nn.Module):
             fc = (x, None, 0, T) if (nograd and not ncl and is_pristine(self.cross_attn, MultiHeadCrossAttention)
                                      and is_pristine(self.cross_attn.proj, HipLinear)) else None
             ckw = {} if fc is None else {"fuse_residual": fc}
-            y_s = self.cross_attn(self.pre_crs_attn_norm(x), y, y_seqlen, num_cond_latents=ncl, shape=latent_shape, **ckw)
+            pn = self.pre_crs_attn_norm
+            if torch.is_grad_enabled() and is_pristine(pn, LayerNorm_FP32):
+                x_n, x = A.layernorm_affine_fork(x, pn.weight, pn.bias, pn.eps)
+            else:
+                x_n = pn(x)
+            y_s = self.cross_attn(x_n, y, y_seqlen, num_cond_latents=ncl, shape=latent_shape, **ckw)
             x = y_s if fc is not None else A.gate_residual(x, y_s, None, 0, T)
-        x_m = A.adaln_modulate(x, mod, 3, 4, T, self.mod_norm_ffn.eps)
+        x_m, x = A.adaln_modulate_fork(x, mod, 3, 4, T, self.mod_norm_ffn.eps)
         ff = (x, mod, 5, T) if (nograd and is_pristine(self.ffn, FeedForwardSwiGLU) and is_pristine(self.ffn.w2, HipLinear)) else None
         x_s = self.ffn(x_m, **({} if ff is None else {"fuse_residual": ff}))
         x = x_s if ff is not None else A.gate_residual(x, x_s, mod, 5, T)

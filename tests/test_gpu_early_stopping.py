@@ -50,7 +50,7 @@ def test_fm_mse_samples_matches_torch_and_is_deterministic():
     x0b = x0.expand(B, -1, -1, -1, -1).contiguous()
     assert torch.equal(ops.fm_mse_samples(pred, eps, x0b, Tc), got)
     scalar, _ = ops.fm_mse(pred, eps, x0b, Tc, need_grad=False)
-    assert abs(scalar.item() - got.mean().item()) < 1e-6 * got.mean().item() + 1e-9
+    assert abs(scalar.item() - got.mean().item()) < 5e-6 * got.mean().item() + 1e-9   # (the scalar kernel adds with fp32 atomics)
     with pytest.raises(Exception):
         ops.fm_mse_samples(pred, eps.float(), x0, Tc)                    # fp32 noise is refused, not reinterpreted
 
