@@ -343,13 +343,16 @@ __global__ __launch_bounds__(WR* WC * 64) void gemm_nt_kernel(const GemmParams p
 typedef __attribute__((ext_vector_type(4))) float f32x4v;
 
 // ---- epilogue of the 16x16x32 kernels: acc[i][j][e] = C[m = mw + 16 i + (lane & 15)][n = nw + 16 j + 4 (lane >> 4) + e] ----
-template <int TM, int TN, int EPI>
+// ROW_FENCE: a scheduling fence after every 16-row block, for kernels whose accumulators live in AGPRs - without it hipcc
+// hoists all TM x TN accumulator reads (and the address arithmetic of every store) to the top and spills around them.
+template <int TM, int TN, int EPI, bool ROW_FENCE = false>
 __device__ __forceinline__ void gemm16_epilogue(const GemmParams& p, f32x4v (&acc)[TM][TN], int64_t mw, int64_t nw, int r16,
                                                 int q) {
   // ---- epilogue: lane owns row m and 4 consecutive columns per (i, j) ----
   const bool vec = (p.ldc % 4 == 0) && (((uintptr_t)p.c & 15) == 0);
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
+    if constexpr (ROW_FENCE) __builtin_amdgcn_sched_barrier(0);
     const int64_t m = mw + i * 16 + r16;
     if (m >= p.M) continue;
     const float* grow = nullptr;
@@ -951,13 +954,13 @@ static int launch_gemm8p(GemmParams& p, hipStream_t s) {
 #include "gemm4w.h"
 
 // four waves x 128 x 128 (gemm4w.h), persistent over all tiles of the launch
-template <int EPI>
+template <int EPI, int NW>
 static int launch_gemm4w(GemmParams& p, hipStream_t s) {
   p.tiles_m = (int)((p.M + 255) / 256);
   { const char* ge = getenv("LCV_GEMM_GROUP_M"); p.group_m = ge ? atoi(ge) : 6; if (p.group_m < 1) p.group_m = 6; }
   p.tiles_n = (int)((p.N + 255) / 256);
   const size_t lds = 2 * 65536;
-  auto kern = gemm4w_nt_kernel<EPI>;
+  auto kern = gemm4w_nt_kernel<EPI, NW>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
@@ -968,7 +971,7 @@ static int launch_gemm4w(GemmParams& p, hipStream_t s) {
   }
   const int ntiles = p.tiles_m * p.tiles_n;
   p.vid_begin = 0; p.vid_count = ntiles; p.splitk = 1; p.nk_split = 0; p.ws = nullptr;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(ntiles > 256 ? 256 : ntiles)), dim3(256), lds, s, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(ntiles > 256 ? 256 : ntiles)), dim3(NW * 64), lds, s, p);
   LCV_LAUNCH_CHECK("gemm4w_nt");
   return LCV_OK;
 }
@@ -1027,7 +1030,8 @@ static int dispatch_tile(GemmParams& p, hipStream_t s) {
                    (p.nk2 == 0 || ((uint64_t)p.M * p.lda2 * 2 < (1ull << 32) && (uint64_t)p.N * p.ldw2 * 2 < (1ull << 32)));
   if (mode == 6 && ok8) mode = 9;  // persistent workgroups (identical to 8 when there are no more tiles than CUs)
   if (force) mode = force[0] - '0';
-  if (mode == 4 && ok8) return launch_gemm4w<EPI>(p, s);
+  if (mode == 4 && ok8) return launch_gemm4w<EPI, 4>(p, s);
+  if (mode == 5 && ok8) return launch_gemm4w<EPI, 8>(p, s);
   if (mode == 8 && ok8) return launch_gemm8p<EPI, false>(p, s);
   if (mode == 9 && ok8) return launch_gemm8p<EPI, true>(p, s);
   if (mode == 6 || mode == 8 || mode == 9) return launch_gemm16<256, 256, 2, 4, EPI, false>(p, s);

@@ -50,31 +50,40 @@ __device__ __forceinline__ void g4_set_m0(unsigned dst) { asm volatile("s_mov_b3
 __device__ __forceinline__ void g4_dma(unsigned off, const char* base) {
   asm volatile("global_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base) : "memory");
 }
-// gap g of a phase carries read number t (0..15) iff t = floor(2 (g + 1) / 7) - 1 is new: 16 reads over gaps 3..55
-__host__ __device__ constexpr int g4_read_slot(int g) {
-  return (2 * (g + 1) / 7 != 2 * g / 7 && g < 56) ? 2 * (g + 1) / 7 - 1 : -1;
+// NR reads spread over the first 7/8 of a phase of NG MFMAs: gap g carries read t iff t = floor(NR (g + 1) / span) - 1 is new
+__host__ __device__ constexpr int g4_read_slot(int g, int NR, int NG) {
+  const int span = NG * 7 / 8;
+  return (g < span && NR * (g + 1) / span != NR * g / span) ? NR * (g + 1) / span - 1 : -1;
 }
 
-template <int EPI>
-__global__ __launch_bounds__(256) void gemm4w_nt_kernel(const GemmParams p) {
+// NW = 4: one wave per SIMD, 128 x 128 per wave (the design above).  NW = 8: two waves per SIMD, 128 x 64 per wave - the same
+// self-pipelined stream per wave, half the MFMAs / DMA pieces per wave and phase (32 / 4) and 12 fragment reads; the partner wave
+// fills the issue slots a DMA piece or the epilogue takes, at the price of reading every A fragment twice per workgroup.
+template <int EPI, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm4w_nt_kernel(const GemmParams p) {
   constexpr unsigned SLOT = 32768u, W_OFF = 16384u, BUF = 65536u;
+  constexpr int TN = NW == 4 ? 8 : 4;          // 16-column MFMA tiles per wave
+  constexpr int NG = 8 * TN;                   // MFMAs per phase
+  constexpr int NR = 8 + TN;                   // fragment reads per phase
+  constexpr int NP = 16 / NW;                  // DMA pieces per wave, stage and operand
+  constexpr int ROWS = 256 / NW;               // rows of A (and of W) a wave stages
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = NW == 4 ? wave >> 1 : wave >> 2, wc = NW == 4 ? wave & 1 : wave & 3;
   const int r16 = lane & 15, q = lane >> 4;
   const int vid_end = p.vid_begin + p.vid_count;
   const int nk1 = p.nk1, nk = p.nk1 + p.nk2;
   const int stride = (int)gridDim.x;
   const unsigned lds0 = (unsigned)(uintptr_t)(g4_lds_u8*)smem;
-  const unsigned lds_wave = lds0 + (unsigned)wave * 4096u;   // this wave's 64 DMA rows of the A part of slot 0 (W part at + W_OFF)
+  const unsigned lds_wave = lds0 + (unsigned)wave * (unsigned)(ROWS * 64);   // this wave's 64 DMA rows of the A part of slot 0 (W part at + W_OFF)
 
   // ---- staging cursor: the (tile, K tile) whose stages the next DMA blocks fetch (half 0 then half 1 of a K tile: the phases
   // alternate in step with it).  A wave fills rows 64 w .. 64 w + 63 of the A and of the W part of a slot with 4 + 4 instructions
   // of 16 rows x 64 B; source = scalar base (operand + K offset + 64 B for k-half 1) + per-lane 32-bit offset ----
   int st_vid = p.vid_begin + (int)blockIdx.x, st_kt = 0;
-  unsigned voa[4], vow[4];
+  unsigned voa[NP], vow[NP];
   const char* st_a = nullptr;
   const char* st_w = nullptr;
   auto stage_setup = [&]() {
@@ -85,8 +94,8 @@ __global__ __launch_bounds__(256) void gemm4w_nt_kernel(const GemmParams p) {
     st_a = (const char*)(lora ? p.a2 : p.a);
     st_w = (const char*)(lora ? p.w2 : p.w);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int row = 64 * wave + 16 * t + (lane >> 2);
+    for (int t = 0; t < NP; ++t) {
+      const int row = ROWS * wave + 16 * t + (lane >> 2);
       int64_t g = (int64_t)tm * 256 + row;
       voa[t] = (unsigned)(g > p.M - 1 ? p.M - 1 : g) * lda_b + (unsigned)(lane & 3) * 16u;
       g = (int64_t)tn * 256 + row;
@@ -111,39 +120,41 @@ __global__ __launch_bounds__(256) void gemm4w_nt_kernel(const GemmParams p) {
   const unsigned lane_part = (unsigned)(r16 * 64 + q * 16);
   unsigned a_rd0 = lds0 + (unsigned)wr * 8192u + lane_part;            // next read of set 0 (k-half 0): buffer 0
   unsigned a_rd1 = a_rd0;                                             // next read of set 1 (k-half 1, + SLOT by the immediate)
-  unsigned w_rd0 = lds0 + W_OFF + (unsigned)wc * 8192u + lane_part;
+  unsigned w_rd0 = lds0 + W_OFF + (unsigned)wc * (unsigned)(TN * 1024) + lane_part;
   unsigned w_rd1 = w_rd0;
 
-  f32x4v acc[8][8];
-  bf16x8 fa[2][8], fw[2][8];   // [set][i | j]
+  f32x4v acc[8][TN];
+  bf16x8 fa[2][8], fw[2][TN];   // [set][i | j]
 
   auto read_frag = [&](auto set_c, auto t_c) {   // W fragments first: the first MFMA row of a phase needs all of them
     constexpr int S = decltype(set_c)::value, t = decltype(t_c)::value;
     constexpr int half_off = S ? (int)SLOT : 0;
-    if constexpr (t < 8) g4_read<half_off + t * 1024>(fw[S][t], S ? w_rd1 : w_rd0);
-    else g4_read<half_off + (t - 8) * 1024>(fa[S][t - 8], S ? a_rd1 : a_rd0);
+    if constexpr (t < TN) g4_read<half_off + t * 1024>(fw[S][t], S ? w_rd1 : w_rd0);
+    else g4_read<half_off + (t - TN) * 1024>(fa[S][t - TN], S ? a_rd1 : a_rd0);
   };
   // the 8 DMA of one stage (k-half H of the cursor's K tile) into the slot at LDS byte address dst (this wave's rows of it)
   auto dma_one = [&](auto h_c, auto t_c, const char* ab, const char* wb) {
     constexpr int H = decltype(h_c)::value, t = decltype(t_c)::value;
-    if constexpr (t < 4) g4_dma(voa[t], ab + H * 64);
-    else g4_dma(vow[t - 4], wb + H * 64);
+    if constexpr (t < NP) g4_dma(voa[t], ab + H * 64);
+    else g4_dma(vow[t - NP], wb + H * 64);
   };
 
   // One phase: 64 MFMAs on set S; the reads of set S^1; the DMA of k-half H of the cursor's K tile into `dst`.
   auto phase = [&](auto s_c, auto h_c, unsigned dst, const char* ab, const char* wb) {
     constexpr int S = decltype(s_c)::value;
 #if defined(G4_LAB_NO_BARRIER)
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if constexpr (NW == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
 #else
-    asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    if constexpr (NW == 4) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
 #endif
-    g4_static_for<0, 64>([&](auto g_c) {
+    g4_static_for<0, NG>([&](auto g_c) {
       constexpr int g = decltype(g_c)::value;
-      constexpr int i = g >> 3, j = g & 7;
+      constexpr int i = g / TN, j = g % TN;
       constexpr bool is_dma = (g & 7) == 4;
-      constexpr int t_dma = g >> 3, t_rd = g4_read_slot(g);
-      if constexpr (is_dma) g4_set_m0(dst + (t_dma < 4 ? 0u : W_OFF) + (unsigned)(t_dma & 3) * 1024u);
+      constexpr int t_dma = g >> 3, t_rd = g4_read_slot(g, NR, NG);
+      if constexpr (is_dma) g4_set_m0(dst + (t_dma < NP ? 0u : W_OFF) + (unsigned)(t_dma % NP) * 1024u);
       g4_mfma(acc[i][j], fw[S][j], fa[S][i]);
 #ifndef G4_LAB_NO_DMA
       if constexpr (is_dma) dma_one(h_c, std::integral_constant<int, t_dma>{}, ab, wb);
@@ -167,9 +178,9 @@ __global__ __launch_bounds__(256) void gemm4w_nt_kernel(const GemmParams p) {
     const char* ab = st_a + stage_k_bytes();
     const char* wb = st_w + stage_k_bytes();
     const unsigned dst = lds_wave + (dq & 3u) * SLOT;
-    g4_static_for<0, 8>([&](auto t_c) {
+    g4_static_for<0, 2 * NP>([&](auto t_c) {
       constexpr int t = decltype(t_c)::value;
-      g4_set_m0(dst + (t < 4 ? 0u : W_OFF) + (unsigned)(t & 3) * 1024u);
+      g4_set_m0(dst + (t < NP ? 0u : W_OFF) + (unsigned)(t % NP) * 1024u);
       asm volatile("s_nop 0");
       dma_one(h_c, t_c, ab, wb);
     });
@@ -179,8 +190,9 @@ __global__ __launch_bounds__(256) void gemm4w_nt_kernel(const GemmParams p) {
   dma_stage_now(C1{});
   stage_next_k_tile();
   dma_stage_now(C0{});   // the cursor now stands on k-half 1 of K tile 1: what phase 0 issues
-  asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
-  g4_static_for<0, 16>([&](auto t_c) { read_frag(C0{}, t_c); });
+  if constexpr (NW == 4) asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+  g4_static_for<0, NR>([&](auto t_c) { read_frag(C0{}, t_c); });
   a_rd0 ^= BUF;
   w_rd0 ^= BUF;
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -189,7 +201,7 @@ __global__ __launch_bounds__(256) void gemm4w_nt_kernel(const GemmParams p) {
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < TN; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
     asm volatile("s_nop 7" ::: "memory");
     // The previous epilogue's stores read their data registers asynchronously; hipcc would otherwise park an s_waitcnt vmcnt(0)
     // in front of the first fragment read that reuses one of them - INSIDE the K loop, where it would also wait, every K tile,
@@ -209,17 +221,26 @@ __global__ __launch_bounds__(256) void gemm4w_nt_kernel(const GemmParams p) {
       int tm, tn;
       gemm_tile_coords(p, vid, tm, tn);
 #ifdef G4_LAB_TRIVIAL_EPI
-      float* cp = (float*)p.c + ((int64_t)tm * 256 + wr * 128) * p.ldc + (int64_t)tn * 256 + wc * 128 + lane * 4;
+      float* cp = (float*)p.c + ((int64_t)tm * 256 + wr * 128) * p.ldc + (int64_t)tn * 256 + wc * (16 * TN) + lane * 4;
 #pragma unroll
       for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4v*>(cp + (i * 8 + j) * 256) = acc[i][j];
+        for (int j = 0; j < TN; ++j) *reinterpret_cast<f32x4v*>(cp + (i * TN + j) * 256) = acc[i][j];
 #else
-      gemm16_epilogue<8, 8, EPI>(p, acc, (int64_t)tm * 256 + wr * 128, (int64_t)tn * 256 + wc * 128, r16, q);
+      gemm16_epilogue<8, TN, EPI, true>(p, acc, (int64_t)tm * 256 + wr * 128, (int64_t)tn * 256 + wc * (16 * TN), r16, q);
 #endif
     }
     vid += stride;
     if (vid >= vid_end) break;
+    // The next tile's first fragments were read by the last phase; reading them AGAIN here makes those registers dead across
+    // the epilogue (hipcc otherwise keeps 48-64 of them live through it and spills the epilogue's own values to scratch:
+    // 100-250 scratch accesses per tile, each behind a full vmcnt wait - 30-40 us per tile).  One LDS latency per tile.
+    a_rd0 ^= BUF;
+    w_rd0 ^= BUF;
+    g4_static_for<0, NR>([&](auto t_c) { read_frag(C0{}, t_c); });
+    a_rd0 ^= BUF;
+    w_rd0 ^= BUF;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the surplus DMA blocks land before the LDS allocation is released
 }

@@ -28,9 +28,12 @@ int main(int argc, char** argv) {
   p.lda = K; p.ldw = K; p.ldc = N; p.rows_per_frame = 1;
   p.tiles_m = (int)((M + 255) / 256); p.tiles_n = (int)((N + 255) / 256); p.group_m = 6;
   p.vid_begin = 0; p.vid_count = p.tiles_m * p.tiles_n; p.splitk = 1;
-  auto kern = gemm4w_nt_kernel<0>;
+  #ifndef G4_LAB_NW
+#define G4_LAB_NW 4
+#endif
+  auto kern = gemm4w_nt_kernel<0, G4_LAB_NW>;
   (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-  auto run = [&]() { hipLaunchKernelGGL(kern, dim3(256), dim3(256), 131072, 0, p); };
+  auto run = [&]() { hipLaunchKernelGGL(kern, dim3(256), dim3(G4_LAB_NW * 64), 131072, 0, p); };
   for (int i = 0; i < 3; ++i) run();
   if (hipDeviceSynchronize() != hipSuccess) { printf("launch failed\n"); return 1; }
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);

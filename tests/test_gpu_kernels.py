@@ -247,9 +247,10 @@ def test_gemm_four_wave_stream_kernel_bitwise(monkeypatch):
             kw = dict(a2=_randn(M, K2, seed=seed + 3).to(DEV), w2=_randn(N, K2, seed=seed + 4, scale=0.05).to(DEV))
         monkeypatch.setenv("LCV_GEMM_TILE", "6")
         ref = ops.gemm_nt(a, w, b, **kw)
-        monkeypatch.setenv("LCV_GEMM_TILE", "4")
-        for _ in range(3):
-            assert torch.equal(ops.gemm_nt(a, w, b, **kw), ref), (M, N, K, K2)
+        for tile in ("4", "5"):    # 5 = the same stream design on 8 waves (128 x 64 per wave)
+            monkeypatch.setenv("LCV_GEMM_TILE", tile)
+            for _ in range(3):
+                assert torch.equal(ops.gemm_nt(a, w, b, **kw), ref), (M, N, K, K2, tile)
 
 
 @pytest.mark.parametrize("M,N,K,kind", [(12480, 4096, 4096, "plain"), (12480, 4096, 4096, "gate_residual"),
