@@ -34,6 +34,15 @@ WORKLOADS = {  # name: (T_lat, h, w, description)
 MFMA_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+_T0 = time.perf_counter()
+
+
+def progress(msg: str):
+    """One line per stage on stderr (stdout carries exactly one JSON line): a default run takes a few minutes and a
+    silent one looks hung to whoever launched it."""
+    print(f"[bench +{time.perf_counter() - _T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -58,10 +67,12 @@ def cpu_baseline(num_inference_steps: int) -> dict:
     of which 77 valid), full width, 4 Euler steps with CFG off and then 4 with CFG on; in each run the first step is the
     warm-up and the other three are timed (median).  All 48 blocks in fp32 are 54 GB of weights and ~40 s per forward on a
     16-core share, so depth 2 is timed and multiplied by 24 (embedders / head < 0.5 %): a BOUNDED sample, ~25 s of CPU work.
-    Threads = the affinity mask of this process, stated in `cores`."""
+    Threads = min(affinity mask, 16: the CPU share of a one-GPU job), stated in `cores`."""
     from oracle import dit_oracle as orc
     from oracle import pipeline_oracle as porc
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # the affinity mask of a shared GPU host can list every core of the machine while the CPU share of a one-GPU job is 16:
+    # more threads than that only thrash (a 128-thread run of this function did not finish in 7 minutes)
+    cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
     torch.set_num_threads(cores)
     cfg = dict(hidden_size=4096, depth=2, num_heads=32, in_channels=16, out_channels=16, adaln_tembed_dim=512,
                caption_channels=4096, patch_size=(1, 2, 2), ffn_hidden=orc.ffn_hidden_dim(4096),
@@ -85,7 +96,9 @@ def cpu_baseline(num_inference_steps: int) -> dict:
         steps = sorted(b - a for a, b in zip(marks[1:-1], marks[2:]))     # steps 1..3 (step 0 = warm-up)
         return steps[len(steps) // 2]
     step_off = timed_steps(False)
+    progress(f"CPU baseline: CFG-off step {step_off:.2f} s")
     step_on = timed_steps(True)
+    progress(f"CPU baseline: CFG-on step {step_on:.2f} s; TTA steps ...")
     sec_per_step48 = step_on * 24            # 2 -> 48 blocks
     # One LoRA-TTA inner step on the same sample: forward + LoRA-only backward through the same 2 blocks
     # with rank-8 adapters on qkv/proj folded in as W + s*B*A (torch autograd over the oracle), 1 warm-up + 1 timed, x24.
@@ -117,7 +130,7 @@ def cpu_baseline(num_inference_steps: int) -> dict:
             "tta_inner_step_s": round(tta[-1] * 24, 1),
             "sample": f"K1 {WORKLOADS['K1'][3]}, full width, 2 of 48 blocks: 4 Euler steps CFG off, then 4 with CFG 4.0 "
                       "(step 0 of each run = warm-up, median of steps 1-3), oracle/pipeline_oracle.py at the bf16 rounding "
-                      f"points in fp32 math on {cores} threads (= the affinity mask); value = 5 latent frames / "
+                      f"points in fp32 math on {cores} threads (min(affinity mask, 16)); value = 5 latent frames / "
                       f"({num_inference_steps} steps x CFG-on step time x 24 [2 -> 48 blocks]); tta_inner_step_s = one forward + "
                       "LoRA-only backward (rank 8 on qkv+proj) of the same 2 blocks, second of two runs, x24"}
 
@@ -280,7 +293,9 @@ def main():
 
     cpu_base = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        progress("CPU baseline: oracle K1 depth 2, 4 + 4 Euler steps and 2 TTA steps on the host cores ...")
         cpu_base = cpu_baseline(args.num_inference_steps)
+        progress(f"CPU baseline done: {cpu_base['k1_step_s_cfg_on_depth2']} s per CFG step at depth 2")
 
     from lcv_hip import lib, ops
     lib.call("lcv_device_check")
@@ -291,6 +306,7 @@ def main():
     T, h, w, desc = WORKLOADS[args.workload]
     dit = LongCatVideoTransformer3DModel(device=dev, dtype=torch.bfloat16, depth=args.depth).eval()
     dit.init_synthetic_(seed=1234)
+    progress(f"DiT built ({args.depth} blocks, synthetic weights); warm-up: {args.warmup} step(s) of {args.workload}")
     pipe = LongCatVideoPipeline(scheduler=FlowMatchEulerDiscreteScheduler(), dit=dit)
     pipe.device = dev
     sp = args.parallelism == "sp" and world > 1
@@ -318,6 +334,7 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    progress(f"timed region: {args.steps} CFG denoise step(s)")
     ops.PROFILE = []  # (start_event, end_event, flops, Nq, Nk, kernel name) per attention launch, recorded on the launch stream
     t0 = time.perf_counter()
     x = run(args.warmup, args.warmup + args.steps, x)
@@ -334,6 +351,7 @@ def main():
     assert torch.isfinite(x).all().item(), "non-finite latents"
 
     sec_per_step = elapsed / args.steps
+    progress(f"timed region done: {sec_per_step:.3f} s per step")
 
     # ---- secondary timings (untimed region): one CFG denoise step at BASELINE configs 2 and 1 (K2 49x480p, K1 16x256x256) ----
     secondary = {}
@@ -348,6 +366,7 @@ def main():
             x2 = run2(1, 3, x2)
             torch.cuda.synchronize()
             secondary[f"{name}_cfg_step_s"] = round((time.perf_counter() - t1) / 2, 4)
+            progress(f"secondary {name}: {secondary[f'{name}_cfg_step_s']} s per CFG step")
             assert torch.isfinite(x2).all().item()
 
     # ---- extras (outside the timed region, rank 0 of a 1-GPU run): the other two legs of "wall-clock per TTA video" ----
@@ -355,9 +374,13 @@ def main():
     if world == 1 and not args.no_extras and args.depth == 48:
         import contextlib
         with contextlib.redirect_stdout(sys.stderr):   # stdout carries exactly one JSON line
+            progress("extras 1/3: the reference's 480p operating point (generation + LoRA TTA)")
             ref_point = measure_reference_point(dit, dev, pe, pm, ne, nm)
+            progress("extras 2/3: VAE decode, then 1 + 20 LoRA-TTA inner steps at the bench resolution")
             extras = measure_extras(dit, dev, T, h, w, pe, pm)
+            progress("extras 3/3: full-model TTA at the 480p operating point")
             ref_point.update(measure_full_tta_reference_point(dit, dev, pe, pm))
+            progress("extras done")
         extras["reference_operating_point_480p_14c14g"] = {k: (round(v, 2) if isinstance(v, float) else v) for k, v in ref_point.items()}
         # 20 measured inner steps + (50 denoise steps at the measured step time) + measured decode
         extras["wall_clock_per_tta_video_s"] = (
