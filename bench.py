@@ -249,8 +249,6 @@ def measure_extras(dit, dev, T, h, w, pe, pm) -> dict:
     out["vae_decode_tflop"] = round(work["flops"] / 1e12, 1)
     out["vae_decode_frac_of_mfma_peak"] = round(work["flops"] / out["vae_decode_s"] / 1e12 / MFMA_PEAK_TFLOPS, 3)
     del vae, z
-    for b in dit.blocks:          # the fused SwiGLU weight copies are inference-only: give their 9 GB to the activations
-        b.ffn._w13 = None
     gc.collect(); torch.cuda.empty_cache()
     for p in dit.parameters():
         p.requires_grad = False

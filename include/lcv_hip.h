@@ -163,7 +163,9 @@ int lcv_attn_bwd(const void* q, const void* k, const void* v, const void* o,
 
 /* ---- projection GEMM (+ bias, + fused LoRA rank-r term, + epilogues) -- */
 #define LCV_EPI_NONE 0        /* c = acc + bias */
-#define LCV_EPI_SWIGLU 1      /* w rows interleaved [32 gate | 32 up]; c[M, N/2] = silu(g)*u */
+#define LCV_EPI_SWIGLU 1      /* w rows interleaved [32 gate | 32 up]; c[M, N/2] = silu(g)*u.  A non-NULL `resid` is an OUTPUT here:
+                               * bf16 [M, N], the pre-activation (gate | up) rows in the weight's column order, kept for
+                               * lcv_swiglu_bwd_interleaved (training) */
 #define LCV_EPI_GATE_RESIDUAL 2 /* c = resid + gate[b,t,:]*(acc+bias) (fp32), rows are tokens */
 #define LCV_EPI_GELU_TANH 3   /* c = gelu_tanh(acc + bias) */
 #define LCV_EPI_SILU 4        /* c = silu(acc + bias) */
@@ -212,6 +214,9 @@ int lcv_swiglu_fwd(const void* gate, const void* up, void* out, int64_t rows, in
                    int64_t ld_in, void* stream);
 int lcv_swiglu_bwd(const void* gate, const void* up, const void* dout, void* dgate, void* dup,
                    int64_t rows, int64_t F, int64_t ld_in, void* stream);
+/* The backward on the fused layout: gu [rows, 2F] = per 64 columns 32 gate values then their 32 up partners (what
+ * lcv_gemm_nt writes through `resid` under LCV_EPI_SWIGLU); dgu [rows, 2F] gets the gradients in the same layout. */
+int lcv_swiglu_bwd_interleaved(const void* gu, const void* dout, void* dgu, int64_t rows, int64_t F, void* stream);
 
 /* ---- patchify / unpatchify ------------------------------------------ */
 /* x [B,Cin,T,H,W] bf16 -> tokens [B, T*(H/2)*(W/2), Kpad] bf16, k = c*4 + ph*2 + pw (conv3d weight

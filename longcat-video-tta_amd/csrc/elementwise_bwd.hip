@@ -433,6 +433,46 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* __restric
   }
 }
 
+// The same on the fused GEMM's layout: `gu` [rows, 2F] holds, per 64 columns, 32 gate values then their 32 up partners
+// (LCV_EPI_SWIGLU's auxiliary output); `dgu` gets the gradients in that layout, ready to be the A operand of ONE GEMM
+// against the transposed interleaved weight (dx = dgate W1 + dup W3 without a second GEMM and an add).
+__global__ __launch_bounds__(256) void swiglu_bwd_il_kernel(const bf16_t* __restrict__ gu, const bf16_t* __restrict__ dout,
+                                                            bf16_t* __restrict__ dgu, int64_t rows, int fpk) {
+  const int64_t n_packets = rows * fpk;
+  for (int64_t pk = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; pk < n_packets;
+       pk += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = pk / fpk;
+    const int c = (int)(pk - row * fpk) * 8;                       // feature index
+    const int64_t at = row * (int64_t)(fpk * 16) + (c >> 5) * 64 + (c & 31);   // its gate column in the interleaved row
+    float g[8], u[8], d[8], og[8], ou[8];
+    unpack8(*reinterpret_cast<const u16x8*>(gu + at), g);
+    unpack8(*reinterpret_cast<const u16x8*>(gu + at + 32), u);
+    unpack8(*reinterpret_cast<const u16x8*>(dout + pk * 8), d);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float sig = 1.0f / (1.0f + __expf(-g[i]));
+      const float s = g[i] * sig;
+      ou[i] = d[i] * bfround(s);
+      og[i] = d[i] * u[i] * (sig * (1.0f + g[i] * (1.0f - sig)));
+    }
+    *reinterpret_cast<u16x8*>(dgu + at) = pack8(og);
+    *reinterpret_cast<u16x8*>(dgu + at + 32) = pack8(ou);
+  }
+}
+
+extern "C" int lcv_swiglu_bwd_interleaved(const void* gu, const void* dout, void* dgu, int64_t rows, int64_t F, void* stream) {
+  LCV_CHECK_ARG(gu && dout && dgu, "swiglu_bwd_interleaved: null pointer");
+  LCV_CHECK_ARG(F % 32 == 0, "swiglu_bwd_interleaved: F=%ld must be a multiple of 32", (long)F);
+  const int64_t n_packets = rows * (F / 8);
+  if (n_packets == 0) return LCV_OK;
+  int64_t blocks = (n_packets + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(swiglu_bwd_il_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)gu,
+                     (const bf16_t*)dout, (bf16_t*)dgu, rows, (int)(F / 8));
+  LCV_LAUNCH_CHECK("swiglu_bwd_interleaved");
+  return LCV_OK;
+}
+
 extern "C" int lcv_swiglu_bwd(const void* gate, const void* up, const void* dout, void* dgate, void* dup,
                               int64_t rows, int64_t F, int64_t ld_in, void* stream) {
   LCV_CHECK_ARG(gate && up && dout && dgate && dup, "swiglu_bwd: null pointer");
@@ -596,14 +636,17 @@ __global__ __launch_bounds__(256) void tn_skinny_kernel(const bf16_t* __restrict
     for (int e = 0; e < 8; ++e) acc[rr][e] = 0.f;
   const int q = (rpb + 3) / 4;                            // rows per wave (rpb % 4 == 0)
   const int mb = wave * q, me = min(mb + q, nrows);
-  if (k < K) {
-    for (int m = mb; m < me; m += 8) {
-      u16x8 raw[8];
+  if (k < K && mb < me) {
+    // Two batches of 8 rows in flight: the loads of batch i+1 are issued before the 512 FMAs of batch i (with one wave per
+    // SIMD and load -> wait -> compute the kernel sat at ~1 TB/s: nothing was in flight while a wave computed).
+    auto load8 = [&](u16x8 (&raw)[8], int m) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int mm = m + u < me ? m + u : me - 1;       // clamped address; its weight is zeroed below
+        const int mm = m + u < me ? m + u : me - 1;       // clamped address; its weight is zeroed in fma8
         raw[u] = *reinterpret_cast<const u16x8*>(x + (m0 + mm) * ldx + k);
       }
+    };
+    auto fma8 = [&](const u16x8 (&raw)[8], int m) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         float xf[8];
@@ -615,6 +658,16 @@ __global__ __launch_bounds__(256) void tn_skinny_kernel(const bf16_t* __restrict
 #pragma unroll
           for (int e = 0; e < 8; ++e) acc[rr][e] += gv * xf[e];
         }
+      }
+    };
+    u16x8 ra[8], rb[8];
+    load8(ra, mb);
+    for (int m = mb; m < me; m += 16) {
+      if (m + 8 < me) load8(rb, m + 8);
+      fma8(ra, m);
+      if (m + 8 < me) {
+        if (m + 16 < me) load8(ra, m + 16);
+        fma8(rb, m + 8);
       }
     }
   }
@@ -648,7 +701,9 @@ extern "C" int lcv_tn_skinny(const void* g, const void* x, float* out, int64_t M
   LCV_CHECK_ARG(g && x && out, "tn_skinny: null pointer");
   LCV_CHECK_ARG(K % 8 == 0 && ldx % 8 == 0 && R >= 1 && R <= Rpad, "tn_skinny: bad shape");
   if (M == 0) return LCV_OK;
-  int64_t rpb = ((M + 31) / 32 + 3) / 4 * 4;              // ~32 row groups per call
+  // ~32 row groups per call; ~64 when there are few column blocks (K <= 4096: 8), so that two workgroups share a CU
+  const int64_t groups = (K + 511) / 512 <= 8 ? 64 : 32;
+  int64_t rpb = ((M + groups - 1) / groups + 3) / 4 * 4;
   if (rpb > TN_MAXROWS) rpb = TN_MAXROWS;
   if (rpb < 64) rpb = 64;
   const dim3 grid((unsigned)((K + 511) / 512), (unsigned)((M + rpb - 1) / rpb));

@@ -132,6 +132,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p,
             const float gv = bfround(acc[i][2 * jj][4 * g + e] + bg);
             const float uv = bfround(acc[i][2 * jj + 1][4 * g + e] + bu);
             o[e] = f2bf(bfround(silu_f(gv)) * uv);
+            if (p.resid) {   // training: the pre-activation [gate | up] row, in the interleaved weight's own column order
+              bf16_t* aux = const_cast<bf16_t*>(p.resid) + m * p.N;
+              aux[ng + e] = f2bf(gv);
+              aux[ng + 32 + e] = f2bf(uv);
+            }
           }
           if (vec) *reinterpret_cast<u16x4*>(C + f) = o;
           else {
@@ -369,7 +374,7 @@ __device__ __forceinline__ void gemm16_epilogue(const GemmParams& p, f32x4v (&ac
           const int64_t ng = nw + jb * 64 + 16 * u + 4 * q;
           if (ng >= p.N) continue;
           const int64_t f = (nw + jb * 64) / 2 + 16 * u + 4 * q;
-          u16x4 o;
+          u16x4 o, og, ou;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const float bg = p.bias ? bf2f(p.bias[ng + e]) : 0.f;
@@ -377,6 +382,18 @@ __device__ __forceinline__ void gemm16_epilogue(const GemmParams& p, f32x4v (&ac
             const float gv = bfround(acc[i][4 * jb + u][e] + bg);
             const float uv = bfround(acc[i][4 * jb + 2 + u][e] + bu);
             o[e] = f2bf(bfround(silu_f(gv)) * uv);
+            og[e] = f2bf(gv);
+            ou[e] = f2bf(uv);
+          }
+          if (p.resid) {   // training: the pre-activation [gate | up] row, in the interleaved weight's own column order
+            bf16_t* aux = const_cast<bf16_t*>(p.resid) + m * p.N;
+            if (p.N % 4 == 0 && (((uintptr_t)p.resid & 7) == 0)) {
+              *reinterpret_cast<u16x4*>(aux + ng) = og;
+              *reinterpret_cast<u16x4*>(aux + ng + 32) = ou;
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { aux[ng + e] = og[e]; aux[ng + 32 + e] = ou[e]; }
+            }
           }
           if (vec) *reinterpret_cast<u16x4*>(C + f) = o;
           else {

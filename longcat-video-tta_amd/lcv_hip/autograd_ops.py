@@ -602,9 +602,33 @@ def swiglu(g, u):
     return ops.swiglu(g, u)
 
 
+class _SwiGLUFusedFn(torch.autograd.Function):
+    """silu(x w1^T) * (x w3^T) through the interleaved weight with a backward (frozen FFN under LoRA / delta TTA): the GEMM's
+    epilogue also leaves the pre-activation (gate | up) rows (what the unfused form writes as two tensors anyway), the
+    backward turns dh into d(gate | up) in that layout and ONE GEMM against the resident transposed interleaved weight gives
+    dx - instead of w1, w3, swiglu_fwd forward and two GEMMs plus an add backward."""
+
+    @staticmethod
+    def forward(ctx, x2, w13):
+        gu = torch.empty((x2.shape[0], w13.shape[0]), dtype=BF16, device=x2.device)
+        h = ops.gemm_nt(x2, w13, None, epilogue=LCV_EPI_SWIGLU, swiglu_aux=gu)
+        ctx.save_for_backward(gu, w13)
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        gu, w13 = ctx.saved_tensors
+        dgu = ops.swiglu_bwd_interleaved(gu, dh if dh.is_contiguous() else dh.contiguous())
+        return ops.gemm_nt(dgu, transposed_weight(w13), None), None
+
+
 def swiglu_fused(x2: torch.Tensor, w13: torch.Tensor) -> torch.Tensor:
-    """silu(x w1^T) * (x w3^T) in one GEMM (interleaved weight, epilogue in registers); inference only."""
-    return ops.gemm_nt(x2 if x2.is_contiguous() else x2.contiguous(), w13, None, epilogue=LCV_EPI_SWIGLU)
+    """silu(x w1^T) * (x w3^T) in one GEMM (interleaved weight, epilogue in registers).  `w13` is a frozen copy: with a
+    gradient wanted for x the differentiable form runs; a trainable w1 / w3 never comes here (layers.FeedForwardSwiGLU)."""
+    x2 = x2 if x2.is_contiguous() else x2.contiguous()
+    if torch.is_grad_enabled() and x2.requires_grad:
+        return _SwiGLUFusedFn.apply(x2, w13)
+    return ops.gemm_nt(x2, w13, None, epilogue=LCV_EPI_SWIGLU)
 
 
 # --------------------------------------------------------------------------- patch embed / unpatchify

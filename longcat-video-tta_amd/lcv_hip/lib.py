@@ -34,6 +34,7 @@ _SIGNATURES = {
     "lcv_timestep_embedding": [P, P, I64, I64, F32, P],
     "lcv_swiglu_fwd": [P, P, P, I64, I64, I64, P],
     "lcv_swiglu_bwd": [P, P, P, P, P, I64, I64, I64, P],
+    "lcv_swiglu_bwd_interleaved": [P, P, P, I64, I64, P],
     "lcv_patchify": [P, P, I64, I64, I64, I64, I64, I64, P],
     "lcv_unpatchify": [P, P, I64, I64, I64, I64, I64, I, P],
     "lcv_unpatchify_bwd": [P, P, I64, I64, I64, I64, I64, P],

@@ -172,12 +172,18 @@ def _ensure_gemm_workspace(device: torch.device) -> None:
         _GEMM_WS[idx] = ws
 
 
+# Bumped by every fused optimizer step: those kernels write parameters through raw pointers, which never touches a tensor's
+# `_version`.  Whoever caches something derived from TRAINABLE weights (the interleaved SwiGLU weight) keys it on this.
+PARAM_EPOCH = 0
+
+
 def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *,
             a2: Optional[torch.Tensor] = None, w2: Optional[torch.Tensor] = None,
             epilogue: int = LCV_EPI_NONE, out_f32: bool = False, resid: Optional[torch.Tensor] = None,
             mod: Optional[torch.Tensor] = None, gate_idx: int = 0, rows_per_frame: int = 1,
-            out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """c[M,N] = a[M,K] @ w[N,K]^T (+ a2 @ w2^T) + bias with a fused epilogue."""
+            out: Optional[torch.Tensor] = None, swiglu_aux: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """c[M,N] = a[M,K] @ w[N,K]^T (+ a2 @ w2^T) + bias with a fused epilogue.  `swiglu_aux` (SwiGLU epilogue only): a
+    contiguous bf16 [M, N] tensor that receives the pre-activation (gate | up) rows for the backward."""
     _req(a, BF16, "gemm_nt.a"); _req(w, BF16, "gemm_nt.w")
     if a.shape[0] >= 2048:
         _ensure_gemm_workspace(a.device)
@@ -201,6 +207,11 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = Non
         out = torch.empty((M, n_out), dtype=F32 if out_f32 else BF16, device=a.device)
     if bias is not None:
         _req(bias, BF16, "gemm_nt.bias")
+    if swiglu_aux is not None:
+        _req(swiglu_aux, BF16, "gemm_nt.swiglu_aux")
+        if epilogue != LCV_EPI_SWIGLU or resid is not None or swiglu_aux.shape != (M, N) or not swiglu_aux.is_contiguous():
+            raise _lib.LcvError("gemm_nt: swiglu_aux needs the SwiGLU epilogue and a contiguous [M, N] tensor")
+        resid = swiglu_aux          # the C entry point takes it through `resid` (an output under this epilogue)
     C = N
     mod_stride = 0
     if mod is not None:
@@ -415,6 +426,17 @@ def swiglu_bwd(gate, up, dout):
     return dg, du
 
 
+def swiglu_bwd_interleaved(gu: torch.Tensor, dout: torch.Tensor) -> torch.Tensor:
+    """d[gate | up] (interleaved, [rows, 2F]) from the fused GEMM's saved pre-activations and dh [rows, F]."""
+    _req(gu, BF16, "swiglu_bwd_interleaved.gu"); _req(dout, BF16, "swiglu_bwd_interleaved.dout")
+    rows, F2 = gu.shape
+    if not (gu.is_contiguous() and dout.is_contiguous() and dout.shape == (rows, F2 // 2)):
+        raise _lib.LcvError("swiglu_bwd_interleaved: gu [rows, 2F] and dout [rows, F] must be contiguous")
+    dgu = torch.empty_like(gu)
+    call("lcv_swiglu_bwd_interleaved", _ptr(gu), _ptr(dout), _ptr(dgu), rows, F2 // 2, _stream())
+    return dgu
+
+
 def unpatchify_bwd(dout, Cout, T, H, W):
     _req(dout, F32, "unpatchify_bwd.dout")
     B = dout.shape[0]
@@ -538,6 +560,8 @@ class FusedAdamWClip:
              _ptr(self._norm_coef) if self._have_coef else None, float(g["lr"]), float(g["betas"][0]),
              float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), self.step_count, _stream())
         self._have_coef = False
+        global PARAM_EPOCH
+        PARAM_EPOCH += 1
 
 
 # ------------------------------------------------------ frame evaluation ---
@@ -718,3 +742,5 @@ class FusedSGDClip(FusedAdamWClip):
         call("lcv_sgd_step", _ptr(d), self._n_active, self._total_chunks, 1 if self.f32 else 0,
              _ptr(self._norm_coef) if self._have_coef else None, float(g["lr"]), float(g["weight_decay"]), _stream())
         self._have_coef = False
+        global PARAM_EPOCH
+        PARAM_EPOCH += 1

@@ -241,13 +241,11 @@ class FeedForwardSwiGLU(nn.Module):
             return None
         if self.hidden_dim % 32:
             return None
-        if self.w1.weight.requires_grad or self.w3.weight.requires_grad:
-            # trainable gate / up weights (full-model TTA): the fused optimizers update them through raw pointers, which
-            # never bumps `_version`, so a cached interleaved copy would silently go stale — the early stopper's no-grad
-            # anchor checks would then score a model whose FFN is frozen at its pre-TTA values.  No cache, no fusion.
-            self._w13 = self._w13_key = None
-            return None
-        key = (self.w1.weight.data_ptr(), self.w3.weight.data_ptr(), self.w1.weight._version, self.w3.weight._version)
+        # Trainable gate / up weights (full-model TTA, or a model nobody froze): the fused optimizers update them through raw
+        # pointers, which never bumps `_version`, so the key carries the optimizers' step counter as well - a cached copy is
+        # rebuilt after any fused step instead of scoring a model whose FFN is frozen at its pre-TTA values.
+        epoch = ops.PARAM_EPOCH if (self.w1.weight.requires_grad or self.w3.weight.requires_grad) else -1
+        key = (self.w1.weight.data_ptr(), self.w3.weight.data_ptr(), self.w1.weight._version, self.w3.weight._version, epoch)
         if self._w13 is None or self._w13_key != key:
             F_, K = self.w1.weight.shape
             with torch.no_grad():
@@ -259,7 +257,10 @@ class FeedForwardSwiGLU(nn.Module):
     def forward(self, x, fuse_residual=None):
         shp = x.shape
         x2 = x.reshape(-1, shp[-1])
-        w13 = None if torch.is_grad_enabled() else self.fused_w13()
+        # under autograd the fused form needs FROZEN gate / up weights (its backward has no dW): LoRA / delta / norm TTA
+        pristine = is_pristine(self.w1, HipLinear) and is_pristine(self.w3, HipLinear)   # (a LoRA-wrapped w1 has no .weight)
+        trainable = pristine and (self.w1.weight.requires_grad or self.w3.weight.requires_grad)
+        w13 = None if (not pristine or (torch.is_grad_enabled() and trainable)) else self.fused_w13()
         if w13 is not None:
             h = A.swiglu_fused(x2, w13)
         else:

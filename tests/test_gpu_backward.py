@@ -82,6 +82,47 @@ def test_norm_gate_swiglu_backward():
     assert rel_l2(dg, gf.grad) < 5e-3 and rel_l2(du, uf.grad) < 5e-3
 
 
+def test_fused_swiglu_training_path_matches_the_unfused_form():
+    """FeedForwardSwiGLU under autograd with FROZEN weights (LoRA / delta TTA): one GEMM through the interleaved (w1, w3) copy
+    whose epilogue also keeps the pre-activation rows, `lcv_swiglu_bwd_interleaved`, one GEMM against the transposed
+    interleaved weight.  Against the unfused form (w1, w3, swiglu; two dx GEMMs and an add): the forward is the same bits,
+    dx differs only by the rounding of the two partial dx the unfused form adds in bf16; both against fp32 autograd."""
+    from lcv_hip import autograd_ops as A
+    from longcat_video.modules.layers import FeedForwardSwiGLU
+    M, C = 1000, 256
+    ffn = FeedForwardSwiGLU(C, 4 * C, device=DEV, dtype=BF16)
+    g = torch.Generator().manual_seed(5)
+    for p in ffn.parameters():
+        p.data.copy_((torch.randn(p.shape, generator=g) * 0.05).to(BF16))
+        p.requires_grad = False
+    x = _randn(M, C, seed=6).to(DEV)
+    dy = _randn(M, C, seed=7, scale=0.1).to(DEV)
+    xa = x.clone().requires_grad_(True)
+    ya = ffn(xa)                                                   # fused (weights frozen, grad enabled)
+    ya.backward(dy)
+    assert ffn._w13 is not None and ffn._w13.shape == (2 * ffn.hidden_dim, C)
+    xb = x.clone().requires_grad_(True)
+    hb = A.swiglu(ffn.w1(xb), ffn.w3(xb))                          # the unfused form, spelled out
+    yb = ffn.w2(hb)
+    yb.backward(dy)
+    assert torch.equal(ya, yb)
+    xr = x.float().clone().requires_grad_(True)
+    w1, w2, w3 = (m.weight.float() for m in (ffn.w1, ffn.w2, ffn.w3))
+    gr = (xr @ w1.t()).to(BF16).float(); ur = (xr @ w3.t()).to(BF16).float()
+    # straight-through rounding for the reference gradient: same values, smooth graph
+    g_s = xr @ w1.t(); u_s = xr @ w3.t()
+    h_ref = torch.nn.functional.silu(g_s) * u_s
+    (h_ref @ w2.t()).backward(dy.float())
+    e_fused, e_unfused = rel_l2(xa.grad, xr.grad), rel_l2(xb.grad, xr.grad)
+    print(f"dx rel-L2 vs fp32 autograd: fused {e_fused:.2e}, unfused {e_unfused:.2e}; fused vs unfused {rel_l2(xa.grad, xb.grad):.2e}")
+    assert e_fused < 1e-2 and e_fused <= 1.2 * e_unfused + 1e-4
+    # trainable gate / up weights never take the fused form under autograd (it has no dW)
+    ffn.w1.weight.requires_grad = True
+    xc = x.clone().requires_grad_(True)
+    ffn(xc).backward(dy)
+    assert ffn.w1.weight.grad is not None and rel_l2(xc.grad, xb.grad) < 1e-6
+
+
 def test_qknorm_rope_backward():
     from lcv_hip import ops
     from oracle import dit_oracle as orc
