@@ -197,10 +197,12 @@ int lcv_lora_down(const void* x, const void* A, void* h, int64_t M, int64_t K, i
  *   dx = dy W + g A            -> lcv_gemm_nt(dy, W^T, a2 = g, w2 = A^T)
  *   dA[R,K]   = g^T x          -> lcv_tn_skinny(g, x)
  *   dB^T[R,N] = s * h^T dy     -> lcv_tn_skinny(h, dy, scale = s)
- * out[r,k] += scale * sum_m g[m,r] x[m,k]; g: [M,Rpad] bf16, x: [M,K] bf16 (row stride ldx), out: [R,K] fp32,
- * accumulated with fp32 atomics (caller zero-fills). */
+ * out[r,k] = scale * sum_m g[m,r] x[m,k]; g: [M,Rpad] bf16, x: [M,K] bf16 (row stride ldx), out: [R,K] fp32.
+ * ws (16-byte aligned, >= lcv_tn_skinny_ws_bytes(M, K, R)): per-row-group partial sums + a fixed-order reduction, `out` is
+ * overwritten (bit-reproducible).  ws == NULL: accumulated into `out` with fp32 atomics (caller zero-fills). */
 int lcv_tn_skinny(const void* g, const void* x, float* out, int64_t M, int64_t K, int64_t R, int64_t Rpad,
-                  int64_t ldx, float scale, void* stream);
+                  int64_t ldx, float scale, float* ws, int64_t ws_bytes, void* stream);
+int64_t lcv_tn_skinny_ws_bytes(int64_t M, int64_t K, int64_t R);
 /* fp32 islands (t_embedder MLP, adaLN_modulation under the upstream fp32 autocast; run_delta_a.py:161-165):
  * out[M,N] fp32 = act_in(a[M,K] fp32) @ w[N,K]^T (bf16 weights widened) + bias;  act_in: 0 none, 1 SiLU. */
 int lcv_linear_f32_smallm(const float* a, const void* w, const void* bias, float* out, int64_t M, int64_t N,

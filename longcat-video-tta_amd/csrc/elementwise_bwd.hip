@@ -617,7 +617,8 @@ extern "C" int lcv_linear_f32_smallm_bwd(const float* dy, const void* w, const f
 template <int RC>
 __global__ __launch_bounds__(256) void tn_skinny_kernel(const bf16_t* __restrict__ g, const bf16_t* __restrict__ x,
                                                         float* __restrict__ out, int64_t M, int64_t K, int R,
-                                                        int Rpad, int64_t ldx, int r0, float scale, int rpb) {
+                                                        int Rpad, int64_t ldx, int r0, float scale, int rpb,
+                                                        float* __restrict__ part) {
   __shared__ float smem[3 * 64 * RC * 8];                 // 48 KB: first the g rows [rpb][RC], then 3 waves' partials
   static_assert(3 * 64 * RC * 8 >= TN_MAXROWS * RC, "LDS image too small for the g rows");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -629,34 +630,39 @@ __global__ __launch_bounds__(256) void tn_skinny_kernel(const bf16_t* __restrict
     smem[i] = (m < nrows && r0 + rr < R) ? bf2f(g[(m0 + m) * Rpad + r0 + rr]) : 0.f;
   }
   __syncthreads();
-  float acc[RC][8];
+  typedef __attribute__((ext_vector_type(2))) float f32x2;
+  f32x2 acc[RC][4];                                        // packed pairs of columns: v_pk_fma_f32 (32 per row instead of 64)
 #pragma unroll
   for (int rr = 0; rr < RC; ++rr)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[rr][e] = 0.f;
-  const int q = (rpb + 3) / 4;                            // rows per wave (rpb % 4 == 0)
-  const int mb = wave * q, me = min(mb + q, nrows);
+    for (int e = 0; e < 4; ++e) acc[rr][e] = f32x2{0.f, 0.f};
+  const int q = rpb / 4;                                   // rows per wave (rpb % 32 == 0: whole batches of 8, so a batch never
+  const int mb = wave * q, me = min(mb + q, nrows);        // reaches into the next wave's rows; rows >= nrows have g = 0 in LDS)
   if (k < K && mb < me) {
-    // Two batches of 8 rows in flight: the loads of batch i+1 are issued before the 512 FMAs of batch i (with one wave per
+    // Two batches of 8 rows in flight: the loads of batch i+1 are issued before the FMAs of batch i (with one wave per
     // SIMD and load -> wait -> compute the kernel sat at ~1 TB/s: nothing was in flight while a wave computed).
     auto load8 = [&](u16x8 (&raw)[8], int m) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int mm = m + u < me ? m + u : me - 1;       // clamped address; its weight is zeroed in fma8
+        const int mm = m + u < nrows ? m + u : nrows - 1;  // clamped address; its weight in LDS is zero
         raw[u] = *reinterpret_cast<const u16x8*>(x + (m0 + mm) * ldx + k);
       }
     };
     auto fma8 = [&](const u16x8 (&raw)[8], int m) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        float xf[8];
-        unpack8(raw[u], xf);
-        const bool live = m + u < me;
+        f32x2 xf[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xf[e] = f32x2{bf2f(raw[u][2 * e]), bf2f(raw[u][2 * e + 1])};
+        static_assert(RC == 8, "the g row is read as two float4");
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(smem + (m + u) * RC);
+        const f32x4 g1 = *reinterpret_cast<const f32x4*>(smem + (m + u) * RC + 4);
 #pragma unroll
         for (int rr = 0; rr < RC; ++rr) {
-          const float gv = live ? smem[(m + u) * RC + rr] : 0.f;
+          const float gv = rr < 4 ? g0[rr & 3] : g1[rr & 3];
+          const f32x2 gvv = f32x2{gv, gv};
 #pragma unroll
-          for (int e = 0; e < 8; ++e) acc[rr][e] += gv * xf[e];
+          for (int e = 0; e < 4; ++e) acc[rr][e] = __builtin_elementwise_fma(gvv, xf[e], acc[rr][e]);
         }
       }
     };
@@ -677,7 +683,7 @@ __global__ __launch_bounds__(256) void tn_skinny_kernel(const bf16_t* __restrict
 #pragma unroll
     for (int rr = 0; rr < RC; ++rr)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) dst[rr * 8 + e] = acc[rr][e];
+      for (int e = 0; e < 8; ++e) dst[rr * 8 + e] = acc[rr][e >> 1][e & 1];
   }
   __syncthreads();
   if (wave == 0 && k < K) {
@@ -686,31 +692,63 @@ __global__ __launch_bounds__(256) void tn_skinny_kernel(const bf16_t* __restrict
       if (r0 + rr < R) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          float v = acc[rr][e];
+          float v = acc[rr][e >> 1][e & 1];
 #pragma unroll
           for (int w2 = 0; w2 < 3; ++w2) v += smem[(w2 * 64 + lane) * RC * 8 + rr * 8 + e];
-          atomicAdd(out + (int64_t)(r0 + rr) * K + k + e, v * scale);
+          if (part) part[((int64_t)blockIdx.y * R + r0 + rr) * K + k + e] = v;   // this row group's slice; summed below
+          else atomicAdd(out + (int64_t)(r0 + rr) * K + k + e, v * scale);
         }
       }
     }
   }
 }
 
+// out[r, k] = scale * sum over row groups of part[group][r][k]: a fixed order (bit-reproducible, unlike the atomics), no
+// zero-fill of `out`, and 64 x fewer L2 atomics - with ~64 row groups the atomics were the larger half of the kernel's time
+__global__ __launch_bounds__(256) void tn_skinny_reduce_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                               int64_t n, int groups, float scale) {
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int g = 0; g < groups; ++g) acc += *reinterpret_cast<const f32x4*>(part + (int64_t)g * n + i);
+  *reinterpret_cast<f32x4*>(out + i) = acc * scale;
+}
+
 extern "C" int lcv_tn_skinny(const void* g, const void* x, float* out, int64_t M, int64_t K, int64_t R,
-                             int64_t Rpad, int64_t ldx, float scale, void* stream) {
+                             int64_t Rpad, int64_t ldx, float scale, float* ws, int64_t ws_bytes, void* stream) {
   LCV_CHECK_ARG(g && x && out, "tn_skinny: null pointer");
   LCV_CHECK_ARG(K % 8 == 0 && ldx % 8 == 0 && R >= 1 && R <= Rpad, "tn_skinny: bad shape");
   if (M == 0) return LCV_OK;
   // ~32 row groups per call; ~64 when there are few column blocks (K <= 4096: 8), so that two workgroups share a CU
   const int64_t groups = (K + 511) / 512 <= 8 ? 64 : 32;
-  int64_t rpb = ((M + groups - 1) / groups + 3) / 4 * 4;
+  int64_t rpb = ((M + groups - 1) / groups + 31) / 32 * 32;
   if (rpb > TN_MAXROWS) rpb = TN_MAXROWS;
   if (rpb < 64) rpb = 64;
   const dim3 grid((unsigned)((K + 511) / 512), (unsigned)((M + rpb - 1) / rpb));
+  // with a workspace of >= lcv_tn_skinny_ws_bytes(M, K, R): per-group partial sums + a fixed-order reduction (`out` need not
+  // be zeroed and is overwritten); without: fp32 atomics into a zero-filled `out`
+  const int64_t need = (int64_t)grid.y * R * K * 4;
+  float* part = (ws && ws_bytes >= need && ((uintptr_t)ws % 16) == 0) ? ws : nullptr;
+  LCV_CHECK_ARG(ws == nullptr || part != nullptr, "tn_skinny: workspace of %ld bytes is too small or misaligned (need %ld)",
+                (long)ws_bytes, (long)need);
   for (int r0 = 0; r0 < R; r0 += 8) {
     hipLaunchKernelGGL(tn_skinny_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)g,
-                       (const bf16_t*)x, out, M, K, (int)R, (int)Rpad, ldx, r0, scale, (int)rpb);
+                       (const bf16_t*)x, out, M, K, (int)R, (int)Rpad, ldx, r0, scale, (int)rpb, part);
     LCV_LAUNCH_CHECK("tn_skinny");
   }
+  if (part) {
+    const int64_t n = R * K;   // K % 8 == 0: whole float4s
+    hipLaunchKernelGGL(tn_skinny_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, part,
+                       out, n, (int)grid.y, scale);
+    LCV_LAUNCH_CHECK("tn_skinny_reduce");
+  }
   return LCV_OK;
+}
+
+extern "C" int64_t lcv_tn_skinny_ws_bytes(int64_t M, int64_t K, int64_t R) {
+  const int64_t groups = (K + 511) / 512 <= 8 ? 64 : 32;
+  int64_t rpb = ((M + groups - 1) / groups + 31) / 32 * 32;
+  if (rpb > TN_MAXROWS) rpb = TN_MAXROWS;
+  if (rpb < 64) rpb = 64;
+  return ((M + rpb - 1) / rpb) * R * K * 4;
 }

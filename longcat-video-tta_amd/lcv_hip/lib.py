@@ -29,7 +29,7 @@ _SIGNATURES = {
     "lcv_gemm_set_workspace": [P, I64],
     "lcv_linear_f32_smallm": [P, P, P, P, I64, I64, I64, I, P],
     "lcv_lora_down": [P, P, P, I64, I64, I64, I64, I64, F32, P],
-    "lcv_tn_skinny": [P, P, P, I64, I64, I64, I64, I64, F32, P],
+    "lcv_tn_skinny": [P, P, P, I64, I64, I64, I64, I64, F32, P, I64, P],
     "lcv_linear_f32_smallm_bwd": [P, P, P, P, I64, I64, I64, I, P],
     "lcv_timestep_embedding": [P, P, I64, I64, F32, P],
     "lcv_swiglu_fwd": [P, P, P, I64, I64, I64, P],
@@ -103,6 +103,8 @@ def load():
     lib.lcv_last_error.argtypes = []
     lib.lcv_attn_fwd_last_kernel.restype = c_char_p
     lib.lcv_attn_fwd_last_kernel.argtypes = []
+    lib.lcv_tn_skinny_ws_bytes.restype = c_int64     # a size, not a status
+    lib.lcv_tn_skinny_ws_bytes.argtypes = [I64, I64, I64]
     for name, args in _SIGNATURES.items():
         fn = getattr(lib, name, None)
         if fn is None:

@@ -459,8 +459,11 @@ def tn_skinny(g, x, R, scale=1.0):
     """out[R, K] fp32 = scale * g[:, :R]^T @ x  (g [M, Rpad] bf16, x [M, K] bf16)."""
     _req(g, BF16, "tn_skinny.g"); _req(x, BF16, "tn_skinny.x")
     M, K = x.shape
-    out = torch.zeros((R, K), dtype=F32, device=x.device)
-    call("lcv_tn_skinny", _ptr(g), _ptr(x), _ptr(out), M, K, R, g.shape[1], x.stride(0), float(scale), _stream())
+    out = torch.empty((R, K), dtype=F32, device=x.device)
+    ws_bytes = int(_lib.load().lcv_tn_skinny_ws_bytes(M, K, R))
+    ws = torch.empty((max(ws_bytes, 16) // 4,), dtype=F32, device=x.device)     # per-row-group partial sums (caching allocator)
+    call("lcv_tn_skinny", _ptr(g), _ptr(x), _ptr(out), M, K, R, g.shape[1], x.stride(0), float(scale), _ptr(ws), ws_bytes,
+         _stream())
     return out
 
 
