@@ -145,7 +145,8 @@ int lcv_attn_fwd(const void* q, const void* k, const void* v, void* o, float* ls
  * short-key cross-attention body), and bench.py labels its roofline object with what actually ran. */
 const char* lcv_attn_fwd_last_kernel(void);
 /* Backward (two passes, no atomics: dK/dV per 128-key workgroup, dQ per 256-query workgroup; see csrc/attn_bwd.hip).
- * d_o shares o's strides.  delta_ws: fp32 workspace [B,H,Nq].  accumulate_kv != 0 adds into the existing dk/dv
+ * d_o shares o's strides.  delta_ws: fp32 workspace of B*H*(Nq + 2*roundup(Nq, 32)) floats (delta, then the padded
+ * -lse*log2(e) / -delta rows the second-form pass A streams into LDS).  accumulate_kv != 0 adds into the existing dk/dv
  * (second region of the conditioning split).  dq/dk/dv are addressed like q/k/v with their own strides. */
 int lcv_attn_bwd(const void* q, const void* k, const void* v, const void* o,
                  const void* d_o, const float* lse,

@@ -44,8 +44,11 @@ __device__ __forceinline__ int tile_off_b(int row, int ch) {
 // ---------------------------------------------------------------------------
 // delta[b,h,q] = sum_d dO[b,q,h,d] * O[b,q,h,d]   (16 lanes per (q,h) row)
 // ---------------------------------------------------------------------------
+// Also leaves, behind the B*H*Nq deltas, per (b, h) the two rows the second-form pass A streams into LDS as its accumulators'
+// initial values: nlse2[q] = -lse * log2(e) and ndelta[q] = -delta, each padded to Nqp = roundup(Nq, 32) entries with -inf / 0
+// (a padded query row then contributes P = 0 exactly) - consts[(b*H + h) * 2 * Nqp + {0, Nqp} + q].
 __global__ __launch_bounds__(256) void attn_bwd_delta_kernel(const bf16_t* __restrict__ o,
-                                                             const bf16_t* __restrict__ d_o,
+                                                             const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
                                                              float* __restrict__ delta, int64_t Nq, int H,
                                                              int64_t o_sb, int64_t o_sn, int64_t o_sh,
                                                              int64_t do_sb, int64_t do_sn, int64_t do_sh) {
@@ -70,7 +73,15 @@ __global__ __launch_bounds__(256) void attn_bwd_delta_kernel(const bf16_t* __res
   acc += __shfl_xor(acc, 4, 64);
   acc += __shfl_xor(acc, 2, 64);
   acc += __shfl_xor(acc, 1, 64);
-  if (valid && sub == 0) delta[(b * H + hh) * Nq + qi] = acc;
+  if (valid && sub == 0) {
+    delta[(b * H + hh) * Nq + qi] = acc;
+    const int64_t Nqp = (Nq + 31) / 32 * 32;
+    float* cn = delta + (int64_t)gridDim.z * H * Nq + (b * H + hh) * 2 * Nqp;
+    cn[qi] = -lse[(b * H + hh) * Nq + qi] * 1.4426950408889634f;
+    cn[Nqp + qi] = -acc;
+    if (qi == Nq - 1)
+      for (int64_t x = Nq; x < Nqp; ++x) { cn[x] = -INFINITY; cn[Nqp + x] = 0.f; }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -465,14 +476,14 @@ extern "C" int lcv_attn_bwd(const void* q, const void* k, const void* v, const v
   {
     const int64_t rows = Nq * H;
     hipLaunchKernelGGL(attn_bwd_delta_kernel, dim3((unsigned)((rows + 15) / 16), 1, (unsigned)B), dim3(256), 0, s,
-                       (const bf16_t*)o, (const bf16_t*)d_o, delta_ws, Nq, (int)H, o_sb, o_sn, o_sh, o_sb, o_sn, o_sh);
+                       (const bf16_t*)o, (const bf16_t*)d_o, lse, delta_ws, Nq, (int)H, o_sb, o_sn, o_sh, o_sb, o_sn, o_sh);
     LCV_LAUNCH_CHECK("attn_bwd_delta");
   }
   const char* bve = getenv("LCV_ATTN_BWD_VAR");  // A/B knob: bit 0 = second-form pass B (dQ), bit 1 = second-form pass A (dK, dV)
   const int bvar = bve ? (bve[0] - '0') & 3 : 3;
   const bool unit = p.scale_log2e > 1.0f - 4e-7f && p.scale_log2e < 1.0f + 4e-7f;
   if (unit && (bvar & 2)) {
-    const int rc = attn_bwd_dkv2_launch(q, k, v, d_o, lse, delta_ws, dk, dv, accumulate_kv, B, H, Nq, Nk, q_sb, q_sn, q_sh, k_sb, k_sn,
+    const int rc = attn_bwd_dkv2_launch(q, k, v, d_o, lse, delta_ws + B * H * Nq /* the padded -lse2 / -delta rows */, dk, dv, accumulate_kv, B, H, Nq, Nk, q_sb, q_sn, q_sh, k_sb, k_sn,
                                         k_sh, v_sb, v_sn, v_sh, o_sb, o_sn, o_sh, dk_sb, dk_sn, dk_sh, dv_sb, dv_sn, dv_sh, scale, s);
     if (rc != LCV_OK) return rc;
   } else {

@@ -24,7 +24,7 @@ struct AttnBwdDkv2Params {
   const bf16_t* v;
   const bf16_t* d_o;
   const float* lse;
-  const float* delta;
+  const float* consts;   // per (b, h): nlse2[Nqp] | ndelta[Nqp] (attn_bwd_delta_kernel), Nqp = roundup(Nq, 32)
   bf16_t* dk;
   bf16_t* dv;
   int64_t Nq, Nk;
@@ -34,10 +34,15 @@ struct AttnBwdDkv2Params {
   float scale;
   int accumulate_kv;
   int gx, xcd_remap;   // blocks per (batch, head); head-per-XCD block order (speed only: see attn_fwd.hip)
+  int stagger;         // s_sleep argument (x 64 cycles) for every second resident workgroup; 0 = off
 };
 
 __device__ __forceinline__ int swz_k2(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 
+// PIPE: the fragment reads of k-step ks+1 (and of transposed-read step j+1) are issued BEFORE the MFMAs of step ks (j), pinned
+// with scheduling fences.  hipcc's own order is {3 reads; wait; 2 MFMAs} x 8 - every MFMA pair behind a full LDS latency,
+// which the partner wave only half hides (matrix pipe 0.47 busy, profiles/r02_attn_pmc_summary.md).
+template <bool PIPE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dkv2_kernel(const AttnBwdDkv2Params p) {
   constexpr int QT = 32;
   constexpr int TILE_BYTES = QT * 256;                  // one [32][128] bf16 tile
@@ -89,38 +94,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // ---- Q / dO tile staging by DMA (2 + 2 pieces per wave), -lse / -delta through two registers of the first 32 threads ----
   const bf16_t* qbase = p.q + b * p.q_sb + (int64_t)head * p.q_sh;
   const bf16_t* dobase = p.d_o + b * p.o_sb + (int64_t)head * p.o_sh;
-  const float* lsebase = p.lse + (b * p.H + head) * p.Nq;
-  const float* delbase = p.delta + (b * p.H + head) * p.Nq;
-  int dma_row[2], dma_col[2];
+  const int64_t Nqp = (p.Nq + 31) / 32 * 32;
+  const char* cbase_u = lcv_uniform_ptr(p.consts + (b * p.H + head) * 2 * Nqp);
+  const unsigned coff = (unsigned)((lane < 32 ? lane : Nqp + lane - 32) * 4);   // one dword piece: 32 x nlse2 | 32 x ndelta
+  int dma_row[2];
+  unsigned qoff[2], dooff[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     dma_row[i] = 8 * wave + 4 * i + (lane >> 4);
-    dma_col[i] = 8 * ((lane & 15) ^ swz_k2(dma_row[i]));
+    const int col = 8 * ((lane & 15) ^ swz_k2(dma_row[i]));
+    qoff[i] = (unsigned)((dma_row[i] * p.q_sn + col) * 2);
+    dooff[i] = (unsigned)((dma_row[i] * p.o_sn + col) * 2);
   }
-  float lreg = 0.f, dlreg = 0.f;
+  const char* qbase_u = lcv_uniform_ptr(qbase);
+  const char* dobase_u = lcv_uniform_ptr(dobase);
+  const unsigned stage_addr0 = (unsigned)(uintptr_t)lds;
   auto load_tile = [&](int64_t q0, int buf) {
-    lds_u8* sb = lds + buf * STAGE + wave * 2048;
+    // asm-issued (lcv_common.h: a builtin DMA would be waited for before the next fragment read); waited for before the barrier.
+    // Source = scalar tile base + a per-lane 32-bit offset that never changes; the ragged last tile clamps rows per lane.
+    const unsigned sb = stage_addr0 + (unsigned)(buf * STAGE) + (unsigned)wave * 2048u;
+    const char* qt = qbase_u + q0 * (2 * p.q_sn);
+    const char* dt = dobase_u + q0 * (2 * p.o_sn);
+    if (q0 + QT <= p.Nq) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      int64_t row = q0 + dma_row[i];
-      if (row > p.Nq - 1) row = p.Nq - 1;
-      __builtin_amdgcn_global_load_lds((gbl_void_k*)(qbase + row * p.q_sn + dma_col[i]), (lds_void_k*)(sb + 1024 * i), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gbl_void_k*)(dobase + row * p.o_sn + dma_col[i]), (lds_void_k*)(sb + TILE_BYTES + 1024 * i),
-                                       16, 0, 0);
+      for (int i = 0; i < 2; ++i) {
+        lcv_lds_dma16_sv(qoff[i], qt, sb + 1024u * i);
+        lcv_lds_dma16_sv(dooff[i], dt, sb + (unsigned)TILE_BYTES + 1024u * i);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        int64_t back = q0 + dma_row[i] - (p.Nq - 1);
+        if (back < 0) back = 0;
+        lcv_lds_dma16(qt + qoff[i] - back * p.q_sn * 2, sb + 1024u * i);
+        lcv_lds_dma16(dt + dooff[i] - back * p.o_sn * 2, sb + (unsigned)TILE_BYTES + 1024u * i);
+      }
     }
-    if (tid < QT) {
-      const int64_t row = q0 + tid;
-      // rows past Nq: -lse = -inf makes their P (and dS) exactly zero
-      lreg = (row < p.Nq) ? -lsebase[row] * 1.4426950408889634f : -INFINITY;
-      dlreg = (row < p.Nq) ? -delbase[row] : 0.f;
-    }
-  };
-  auto store_consts = [&](int buf) {
-    if (tid < QT) {
-      lds_u8* sb = lds + buf * STAGE + 2 * TILE_BYTES;
-      *reinterpret_cast<AS3 float*>(sb + tid * 4) = lreg;
-      *reinterpret_cast<AS3 float*>(sb + QT * 4 + tid * 4) = dlreg;
-    }
+    // the tile's row constants, already in accumulator form, by one dword piece (no register round trip, no compiler-visible
+    // load in the loop: its wait would be a vmcnt(0) that also drains the pieces above)
+    if (wave == 0) lcv_lds_dma4_sv(coff, cbase_u + q0 * 4, stage_addr0 + (unsigned)(buf * STAGE + 2 * TILE_BYTES));
   };
 
   // ---- LDS read addresses ----
@@ -142,9 +154,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int e = 0; e < 16; ++e) { dkacc[d][e] = 0.f; dvacc[d][e] = 0.f; }
 
   const int nt = (int)((p.Nq + QT - 1) / QT);
+  if (p.stagger) {   // A/B knob: the second workgroup of a CU (dispatch order: id + 256) starts half a tile late
+    const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if ((lin >> 8) & 1)
+      for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(1);
+  }
   load_tile(0, 0);
-  store_consts(0);
-  __syncthreads();  // (drains the LDS-DMA of the K rows and of tile 0: vmcnt 0)
+  lcv_dma_wait_all();
+  __syncthreads();  // (the LDS-DMA of the K rows and of tile 0 has landed)
 
   for (int t = 0; t < nt; ++t) {
     const int buf = t & 1;
@@ -164,14 +181,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int e = 0; e < 4; ++e) { s[4 * g + e] = l4[e]; dp[4 * g + e] = d4[e]; }
     }
+    if constexpr (PIPE) {
+      bf16x8 aq[2], ad[2], kf[2];
+      auto ld1 = [&](int ks, int st) {
+        const int co = 16 * ((2 * ks + h) ^ rf);
+        aq[st] = *reinterpret_cast<const AS3 bf16x8*>(qb + row_off + co);
+        kf[st] = *reinterpret_cast<const AS3 bf16x8*>(lds_k + krow_off + co);
+        ad[st] = *reinterpret_cast<const AS3 bf16x8*>(db + row_off + co);
+      };
+      ld1(0, 0);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      const int co = 16 * ((2 * ks + h) ^ rf);
-      const bf16x8 aq = *reinterpret_cast<const AS3 bf16x8*>(qb + row_off + co);
-      const bf16x8 ad = *reinterpret_cast<const AS3 bf16x8*>(db + row_off + co);
-      const bf16x8 kfr = *reinterpret_cast<const AS3 bf16x8*>(lds_k + krow_off + co);   // same swizzle term: (32 w + r) & 15 == r & 15
-      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, kfr, s, 0, 0, 0);
-      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad, vf[ks], dp, 0, 0, 0);
+      for (int ks = 0; ks < 8; ++ks) {
+        if (ks < 7) ld1(ks + 1, (ks + 1) & 1);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[ks & 1], kf[ks & 1], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad[ks & 1], vf[ks], dp, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const int co = 16 * ((2 * ks + h) ^ rf);
+        const bf16x8 aq = *reinterpret_cast<const AS3 bf16x8*>(qb + row_off + co);
+        const bf16x8 ad = *reinterpret_cast<const AS3 bf16x8*>(db + row_off + co);
+        const bf16x8 kfr = *reinterpret_cast<const AS3 bf16x8*>(lds_k + krow_off + co);   // same swizzle term: (32 w + r) & 15 == r & 15
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, kfr, s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad, vf[ks], dp, 0, 0, 0);
+      }
     }
     // ---- P = exp2(S), dS' = P * dP (the scale goes to dK in the epilogue) ----
 #pragma unroll
@@ -188,24 +224,50 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       dsb[1][j] = (__bf16)dp[8 + j];
     }
     // ---- dV^T += dO^T P ; dK^T += Q^T dS'  (A operands by transposed reads of the dO / Q tiles) ----
-#pragma unroll
-    for (int ss = 0; ss < 2; ++ss) {
-#pragma unroll
-      for (int d = 0; d < 4; ++d) {
+    if constexpr (PIPE) {
+      s16x4 tlo[2], thi[2], tlo2[2], thi2[2];
+      auto ld2 = [&](int j, int st) {   // step j = 4 ss + d
+        const int ss = j >> 2, d = j & 3;
         const int dx = 64 * (d ^ q4);
         const int a0 = t_base[0] + 4096 * ss + dx + 16 * t_low[0];
         const int a1 = t_base[1] + 4096 * ss + dx + 16 * t_low[1];
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((AS3 s16x4*)(db + a0));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((AS3 s16x4*)(db + a1));
-        const bf16x8 dof = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        tlo[st] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((AS3 s16x4*)(db + a0));
+        thi[st] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((AS3 s16x4*)(db + a1));
+        tlo2[st] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((AS3 s16x4*)(qb + a0));
+        thi2[st] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((AS3 s16x4*)(qb + a1));
+      };
+      ld2(0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (j < 7) ld2(j + 1, (j + 1) & 1);
+        const int ss = j >> 2, d = j & 3, st = j & 1;
+        const bf16x8 dof = __builtin_bit_cast(bf16x8, __builtin_shufflevector(tlo[st], thi[st], 0, 1, 2, 3, 4, 5, 6, 7));
         dvacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof, pb[ss], dvacc[d], 0, 0, 0);
-        const s16x4 lo2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((AS3 s16x4*)(qb + a0));
-        const s16x4 hi2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((AS3 s16x4*)(qb + a1));
-        const bf16x8 qtf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo2, hi2, 0, 1, 2, 3, 4, 5, 6, 7));
+        const bf16x8 qtf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(tlo2[st], thi2[st], 0, 1, 2, 3, 4, 5, 6, 7));
         dkacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, dsb[ss], dkacc[d], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          const int dx = 64 * (d ^ q4);
+          const int a0 = t_base[0] + 4096 * ss + dx + 16 * t_low[0];
+          const int a1 = t_base[1] + 4096 * ss + dx + 16 * t_low[1];
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((AS3 s16x4*)(db + a0));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((AS3 s16x4*)(db + a1));
+          const bf16x8 dof = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+          dvacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof, pb[ss], dvacc[d], 0, 0, 0);
+          const s16x4 lo2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((AS3 s16x4*)(qb + a0));
+          const s16x4 hi2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((AS3 s16x4*)(qb + a1));
+          const bf16x8 qtf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo2, hi2, 0, 1, 2, 3, 4, 5, 6, 7));
+          dkacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, dsb[ss], dkacc[d], 0, 0, 0);
+        }
       }
     }
-    if (has_next) store_consts(buf ^ 1);
+    if (has_next) lcv_dma_wait_all();   // the next tile, requested at the top of this one, has had the whole tile to land
     __syncthreads();
   }
 
@@ -245,7 +307,7 @@ int attn_bwd_dkv2_launch(const void* q, const void* k, const void* v, const void
                          int64_t dv_sb, int64_t dv_sn, int64_t dv_sh, float scale, hipStream_t s) {
   AttnBwdDkv2Params p;
   p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.d_o = (const bf16_t*)d_o;
-  p.lse = lse; p.delta = delta; p.dk = (bf16_t*)dk; p.dv = (bf16_t*)dv; p.Nq = Nq; p.Nk = Nk; p.H = (int)H;
+  p.lse = lse; p.consts = delta; p.dk = (bf16_t*)dk; p.dv = (bf16_t*)dv; p.Nq = Nq; p.Nk = Nk; p.H = (int)H;
   p.q_sb = q_sb; p.q_sn = q_sn; p.q_sh = q_sh; p.k_sb = k_sb; p.k_sn = k_sn; p.k_sh = k_sh;
   p.v_sb = v_sb; p.v_sn = v_sn; p.v_sh = v_sh; p.o_sb = o_sb; p.o_sn = o_sn; p.o_sh = o_sh;
   p.dk_sb = dk_sb; p.dk_sn = dk_sn; p.dk_sh = dk_sh; p.dv_sb = dv_sb; p.dv_sn = dv_sn; p.dv_sh = dv_sh;
@@ -253,12 +315,16 @@ int attn_bwd_dkv2_launch(const void* q, const void* k, const void* v, const void
   const size_t lds = 128 * 256 + 2 * (2 * 32 * 256 + 2 * 32 * 4);
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)attn_bwd_dkv2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    if (hipFuncSetAttribute((const void*)attn_bwd_dkv2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+        hipFuncSetAttribute((const void*)attn_bwd_dkv2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       lcv_set_error("attn_bwd: cannot raise dynamic LDS");
       return LCV_EDEVICE;
     }
     attr_set = true;
   }
+  { const char* se = getenv("LCV_ATTN_BWD_STAGGER"); p.stagger = se ? atoi(se) : 0; if (p.stagger < 0 || p.stagger > 127) p.stagger = 0; }
+  const char* pe = getenv("LCV_ATTN_BWD_PIPE");   // A/B knob: 0 = hipcc's own read / MFMA order
+  const bool pipe = !(pe && pe[0] == '0');
   const unsigned gx = (unsigned)((Nk + 127) / 128);
   // A/B knob LCV_ATTN_BWD_XCD=1 enables the head-per-XCD block order.  OFF by default: at the K3-TTA shapes (25 200 keys x 32
   // heads) it measured 27.06 vs 26.51 ms per layer in one process - unlike the forward, these passes are not helped by it
@@ -266,7 +332,8 @@ int attn_bwd_dkv2_launch(const void* q, const void* k, const void* v, const void
   p.gx = (int)gx;
   p.xcd_remap = ((B * H) % 8 == 0 && gx >= 8 && xe && xe[0] == '1') ? 1 : 0;
   const dim3 grid = p.xcd_remap ? dim3(gx * (unsigned)(H * B)) : dim3(gx, (unsigned)H, (unsigned)B);
-  hipLaunchKernelGGL(attn_bwd_dkv2_kernel, grid, dim3(256), lds, s, p);
+  if (pipe) hipLaunchKernelGGL(attn_bwd_dkv2_kernel<true>, grid, dim3(256), lds, s, p);
+  else hipLaunchKernelGGL(attn_bwd_dkv2_kernel<false>, grid, dim3(256), lds, s, p);
   LCV_LAUNCH_CHECK("attn_bwd_dkv2");
   return LCV_OK;
 }

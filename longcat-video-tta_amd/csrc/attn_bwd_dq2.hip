@@ -79,35 +79,39 @@ __global__ __launch_bounds__(512) void attn_bwd_dq2_kernel(const AttnBwdDq2Param
     delta_q = p.delta[(b * p.H + head) * p.Nq + qrow];
   }
 
-  // LDS-DMA roles (as attn_fwd.hip): wave w fills rows 8 w .. 8 w + 7 of both tiles, 2 + 2 one-KiB instructions
-  const bf16_t* kdma[2];
-  const bf16_t* vdma[2];
+  // LDS-DMA roles (as attn_fwd.hip): wave w fills rows 8 w .. 8 w + 7 of both tiles, 2 + 2 one-KiB instructions.  Source = a
+  // scalar tile base (advanced one tile per issue by scalar adds) + a per-lane 32-bit byte offset that never changes; issued from
+  // asm (lcv_common.h: a builtin DMA would be waited for before the next fragment read) and waited for at the end of the tile.
+  unsigned koff[2], voff[2];
   int dma_row[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     dma_row[i] = 8 * wave + 4 * i + (lane >> 4);
     const int col = 8 * ((lane & 15) ^ (((dma_row[i] & 3) << 2) | ((dma_row[i] >> 2) & 3)));
-    kdma[i] = kbase + dma_row[i] * p.k_sn + col;
-    vdma[i] = vbase + dma_row[i] * p.v_sn + col;
+    koff[i] = (unsigned)((dma_row[i] * p.k_sn + col) * 2);
+    voff[i] = (unsigned)((dma_row[i] * p.v_sn + col) * 2);
   }
+  const char* kbase_u = lcv_uniform_ptr(kbase);
+  const char* vbase_u = lcv_uniform_ptr(vbase);
+  const unsigned lds_addr0 = (unsigned)(uintptr_t)lds;
   auto dma_tile = [&](int t, int buf, auto full_c) {
     constexpr bool FULL = decltype(full_c)::value;
-    lds_u8* dst = lds + buf * 2 * TILE_BYTES + wave * 2048;
+    const unsigned dst = lds_addr0 + (unsigned)(buf * 2 * TILE_BYTES) + (unsigned)wave * 2048u;
+    const char* kt = kbase_u + (int64_t)t * (128 * p.k_sn);   // scalar: 64 rows x stride x 2 bytes per tile
+    const char* vt = vbase_u + (int64_t)t * (128 * p.v_sn);
     if (FULL || (int64_t)t * 64 + 64 <= p.Nk) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        __builtin_amdgcn_global_load_lds((gbl_void_q*)kdma[i], (lds_void_q*)(dst + 1024 * i), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gbl_void_q*)vdma[i], (lds_void_q*)(dst + TILE_BYTES + 1024 * i), 16, 0, 0);
-        kdma[i] += 64 * p.k_sn;
-        vdma[i] += 64 * p.v_sn;
+        lcv_lds_dma16_sv(koff[i], kt, dst + 1024u * i);
+        lcv_lds_dma16_sv(voff[i], vt, dst + (unsigned)TILE_BYTES + 1024u * i);
       }
-    } else {  // ragged last tile: rows past Nk re-read the last key (masked below)
+    } else {  // ragged last tile (once per workgroup): rows past Nk re-read the last key (masked below)
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         int64_t back = (int64_t)t * 64 + dma_row[i] - (p.Nk - 1);
         if (back < 0) back = 0;
-        __builtin_amdgcn_global_load_lds((gbl_void_q*)(kdma[i] - back * p.k_sn), (lds_void_q*)(dst + 1024 * i), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gbl_void_q*)(vdma[i] - back * p.v_sn), (lds_void_q*)(dst + TILE_BYTES + 1024 * i), 16, 0, 0);
+        lcv_lds_dma16(kt + koff[i] - back * p.k_sn * 2, dst + 1024u * i);
+        lcv_lds_dma16(vt + voff[i] - back * p.v_sn * 2, dst + (unsigned)TILE_BYTES + 1024u * i);
       }
     }
   };
@@ -130,7 +134,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dq2_kernel(const AttnBwdDq2Param
 
   const int nt = (int)((p.Nk + 63) / 64);
   dma_tile(0, 0, std::false_type{});
-  __syncthreads();  // (drains this wave's LDS-DMA: vmcnt 0)
+  lcv_dma_wait_all();
+  __syncthreads();
 
   auto tile_body = [&](const int t, auto buf_c, auto last_c, auto next_full_c) {
     constexpr int buf = decltype(buf_c)::value;
@@ -188,6 +193,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq2_kernel(const AttnBwdDq2Param
         dqacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, dsb[kk], dqacc[d], 0, 0, 0);
       }
     }
+    if (has_next) lcv_dma_wait_all();   // the next tile, requested at the top of this one, has had the whole tile to land
     __syncthreads();
   };
   {

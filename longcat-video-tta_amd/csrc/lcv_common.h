@@ -73,3 +73,41 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+// ---- LDS-DMA from inline asm (device) ----
+// 16 bytes per lane from a per-lane global address to LDS byte address `lds_dst` + 16 * lane (wave-uniform `lds_dst`).
+// Why not __builtin_amdgcn_global_load_lds: hipcc books a builtin LDS-DMA as a pending LDS write and parks an
+// `s_waitcnt vmcnt(0)` in front of the NEXT ds_read - in a double-buffered loop that waits for the tile just requested before
+// the current one is even read (the attention backward passes ran {issue DMA; wait for it; compute} for a round and a half:
+// SQ_WAIT_ANY 0.52 of the wave cycles).  An asm DMA is invisible to that bookkeeping: the CALLER waits (`lcv_dma_wait_all`)
+// before the barrier that publishes the tile.  M0 carries the LDS destination and is restored: hipcc owns it.
+__device__ __forceinline__ void lcv_lds_dma16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
+// the same with a wave-uniform 64-bit base (SGPR pair) + a 32-bit per-lane byte offset: no 64-bit vector address arithmetic
+__device__ __forceinline__ void lcv_lds_dma16_sv(unsigned voff, const char* sbase, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(sbase), "s"(lds_dst)
+               : "memory");
+}
+// 4 bytes per lane (256 B per wave-instruction), same addressing
+__device__ __forceinline__ void lcv_lds_dma4_sv(unsigned voff, const char* sbase, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(sbase), "s"(lds_dst)
+               : "memory");
+}
+// readfirstlane makes the uniformity of a pointer provable, so that an "s" asm operand gets SGPRs
+__device__ __forceinline__ const char* lcv_uniform_ptr(const void* ptr) {
+  const unsigned long long v = (unsigned long long)ptr;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (const char*)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ void lcv_dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }

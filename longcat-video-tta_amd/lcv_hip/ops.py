@@ -409,7 +409,7 @@ def attention_bwd(q, k, v, o, do, lse, dq, dk, dv, scale, accumulate_kv=False):
         do = do.contiguous()
         if do.stride() != o.stride():
             raise _lib.LcvError("attention_bwd: dO must share O's strides")
-    delta = torch.empty((B, H, Nq), dtype=F32, device=q.device)
+    delta = torch.empty((B * H * (Nq + 2 * ((Nq + 31) // 32 * 32)),), dtype=F32, device=q.device)   # lcv_hip.h: delta_ws
     call("lcv_attn_bwd", _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(do), _ptr(lse), _ptr(dq), _ptr(dk), _ptr(dv),
          _ptr(delta), 1 if accumulate_kv else 0, B, H, Nq, Nk,
          q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2),

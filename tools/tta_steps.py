@@ -16,7 +16,7 @@ h,w = (90,160) if len(sys.argv)<3 or sys.argv[2]=="720p" else (60,104)
 dit=LongCatVideoTransformer3DModel(device=dev,dtype=bf,depth=depth).eval(); dit.init_synthetic_()
 for p in dit.parameters(): p.requires_grad=False
 import os
-if os.environ.get('NO_CKPT')!='1':
+if os.environ.get('CKPT')=='1':   # block checkpointing only on request (the inner loop's own choice at this size is off)
     dit.gradient_checkpointing=True; dit._gradient_checkpointing_func=functools.partial(checkpoint,use_reentrant=False)
 mods=inject_lora_into_dit(dit,rank=8,alpha=16.0,target_modules=["qkv","proj"])
 print(count_lora_parameters(mods))
