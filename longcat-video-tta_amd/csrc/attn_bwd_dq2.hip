@@ -2,8 +2,7 @@
 // (scale * log2(e) == 1; attn_fwd.hip, VAR bit 1).  Same geometry as attn_bwd_dq_kernel (8 waves x 32 query rows, 64-key tiles,
 // query on the lane, S^T = K Q^T, dP^T = V dO^T, dQ^T += K^T dS^T), rebuilt like the forward kernel:
 //   * K / V tiles by LDS-DMA from per-lane pointers that advance one tile per iteration (no staging registers, no ds_write);
-//   * tile loop unrolled by two with compile-time buffers, the last (possibly ragged) tile peeled, so the steady-state body has
-//     neither mask code nor ragged-row code;
+//   * the last (possibly ragged) tile peeled, so the steady-state body has neither mask code nor ragged-row code;
 //   * row constants as the initial accumulator (cdna_hip_programming.md, attention backward): the score accumulators START at
 //     -lse (log2 units), so P = exp2(accumulator) needs no multiply-subtract, and the softmax scale is applied once to dQ in the
 //     epilogue instead of to every dS:  dS' = P * (dP - delta)  is 2 vector instructions per score instead of 5.
@@ -32,11 +31,18 @@ struct AttnBwdDq2Params {
   int gx, xcd_remap;   // blocks per (batch, head); head-per-XCD block order (speed only: see attn_fwd.hip)
 };
 
-__global__ __launch_bounds__(512) void attn_bwd_dq2_kernel(const AttnBwdDq2Params p) {
-  constexpr int QROWS = 256;
+// <NW, NS>: waves per workgroup (32 query rows each) and K / V stages.  <8, 4>: one workgroup per CU, DMA three tiles ahead.
+// <4, 2>: TWO workgroups per CU (128 KiB of LDS together) whose barriers are independent - within one workgroup the barrier
+// per tile starts every wave's MFMA phase at the same moment, so one wave's exp / convert work never sits under another's
+// MFMAs (the lockstep the forward kernel had before it was software-pipelined); two workgroups drift apart and overlap, at the
+// price of streaming K / V into LDS twice.
+template <int NW, int NS>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dq2_kernel(const AttnBwdDq2Params p) {
+  constexpr int QROWS = NW * 32;
+  constexpr int NP = 16 / NW;                  // one-KiB DMA pieces per wave, tile and tensor (4 rows each)
   constexpr int TILE_BYTES = 64 * 256;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  lds_u8* lds = (lds_u8*)smem;  // [2][K tile | V tile]
+  lds_u8* lds = (lds_u8*)smem;  // [NS][K tile | V tile]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -61,7 +67,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq2_kernel(const AttnBwdDq2Param
   const bf16_t* vbase = p.v + b * p.v_sb + (int64_t)head * p.v_sh;
 
   bf16x8 qf[8], dof[8];
-  f32x16 sinit;  // -lse (log2 units) of this lane's query in every element: the C operand of each tile's first score MFMA
+  float sinit;   // -lse (log2 units) of this lane's query: every element of the score accumulators starts there
   float delta_q;
   {
     int64_t qrow = q0 + r;
@@ -73,45 +79,46 @@ __global__ __launch_bounds__(512) void attn_bwd_dq2_kernel(const AttnBwdDq2Param
       qf[ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
       dof[ks] = *reinterpret_cast<const bf16x8*>(dp_ + 16 * ks);
     }
-    const float nl = -p.lse[(b * p.H + head) * p.Nq + qrow] * 1.4426950408889634f;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) sinit[e] = nl;
+    sinit = -p.lse[(b * p.H + head) * p.Nq + qrow] * 1.4426950408889634f;
     delta_q = p.delta[(b * p.H + head) * p.Nq + qrow];
   }
 
   // LDS-DMA roles (as attn_fwd.hip): wave w fills rows 8 w .. 8 w + 7 of both tiles, 2 + 2 one-KiB instructions.  Source = a
   // scalar tile base (advanced one tile per issue by scalar adds) + a per-lane 32-bit byte offset that never changes; issued from
   // asm (lcv_common.h: a builtin DMA would be waited for before the next fragment read) and waited for at the end of the tile.
-  unsigned koff[2], voff[2];
-  int dma_row[2];
+  // (<4, 2> is launched only when K and V share their row stride - they are slices of one packed qkv tensor in the product -
+  // and then keeps ONE offset per piece: with eight the loop spilled, and a spill reload's vmcnt wait drains the DMA queue)
+  constexpr bool ONE_OFF = NW == 4;
+  unsigned koff[NP], voff[ONE_OFF ? 1 : NP];
+  auto dma_row_of = [&](int i) { return 4 * NP * wave + 4 * i + (int)(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) >> 4); };
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    dma_row[i] = 8 * wave + 4 * i + (lane >> 4);
-    const int col = 8 * ((lane & 15) ^ (((dma_row[i] & 3) << 2) | ((dma_row[i] >> 2) & 3)));
-    koff[i] = (unsigned)((dma_row[i] * p.k_sn + col) * 2);
-    voff[i] = (unsigned)((dma_row[i] * p.v_sn + col) * 2);
+  for (int i = 0; i < NP; ++i) {
+    const int row = 4 * NP * wave + 4 * i + (lane >> 4);
+    const int col = 8 * ((lane & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+    koff[i] = (unsigned)((row * p.k_sn + col) * 2);
+    if constexpr (!ONE_OFF) voff[i] = (unsigned)((row * p.v_sn + col) * 2);
   }
   const char* kbase_u = lcv_uniform_ptr(kbase);
   const char* vbase_u = lcv_uniform_ptr(vbase);
   const unsigned lds_addr0 = (unsigned)(uintptr_t)lds;
   auto dma_tile = [&](int t, int buf, auto full_c) {
     constexpr bool FULL = decltype(full_c)::value;
-    const unsigned dst = lds_addr0 + (unsigned)(buf * 2 * TILE_BYTES) + (unsigned)wave * 2048u;
+    const unsigned dst = lds_addr0 + (unsigned)(buf * 2 * TILE_BYTES) + (unsigned)wave * (unsigned)(NP * 1024);
     const char* kt = kbase_u + (int64_t)t * (128 * p.k_sn);   // scalar: 64 rows x stride x 2 bytes per tile
     const char* vt = vbase_u + (int64_t)t * (128 * p.v_sn);
     if (FULL || (int64_t)t * 64 + 64 <= p.Nk) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < NP; ++i) {
         lcv_lds_dma16_sv(koff[i], kt, dst + 1024u * i);
-        lcv_lds_dma16_sv(voff[i], vt, dst + (unsigned)TILE_BYTES + 1024u * i);
+        lcv_lds_dma16_sv(ONE_OFF ? koff[i] : voff[ONE_OFF ? 0 : i], vt, dst + (unsigned)TILE_BYTES + 1024u * i);
       }
     } else {  // ragged last tile (once per workgroup): rows past Nk re-read the last key (masked below)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        int64_t back = (int64_t)t * 64 + dma_row[i] - (p.Nk - 1);
+      for (int i = 0; i < NP; ++i) {
+        int64_t back = (int64_t)t * 64 + dma_row_of(i) - (p.Nk - 1);
         if (back < 0) back = 0;
         lcv_lds_dma16(kt + koff[i] - back * p.k_sn * 2, dst + 1024u * i);
-        lcv_lds_dma16(vt + voff[i] - back * p.v_sn * 2, dst + (unsigned)TILE_BYTES + 1024u * i);
+        lcv_lds_dma16(vt + (ONE_OFF ? koff[i] : voff[ONE_OFF ? 0 : i]) - back * p.v_sn * 2, dst + (unsigned)TILE_BYTES + 1024u * i);
       }
     }
   };
@@ -132,21 +139,29 @@ __global__ __launch_bounds__(512) void attn_bwd_dq2_kernel(const AttnBwdDq2Param
 #pragma unroll
     for (int e = 0; e < 16; ++e) dqacc[d][e] = 0.f;
 
+  // K / V stages: a ring of NS = 4 (128 KiB; one workgroup per CU anyway: ~220 registers per wave), the DMA runs three tiles
+  // ahead.  With two stages a tile had one tile's worth of MFMAs (~1.6 us) to land and the waves still waited 45 % of their
+  // cycles; counted waits: at the end of tile t only tile t+1 has to be in, t+2 and t+3 stay in flight (4 pieces each).
+  static_assert((NW == 8 && NS == 4) || (NW == 4 && NS == 2), "the counted waits below are written for these two forms");
   const int nt = (int)((p.Nk + 63) / 64);
-  dma_tile(0, 0, std::false_type{});
-  lcv_dma_wait_all();
+#pragma unroll
+  for (int i = 0; i < NS - 1; ++i)
+    if (i < nt) dma_tile(i, i, std::false_type{});
+  if (NS == 4 && nt >= 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (NS == 4 && nt == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else lcv_dma_wait_all();
   __syncthreads();
 
-  auto tile_body = [&](const int t, auto buf_c, auto last_c, auto next_full_c) {
-    constexpr int buf = decltype(buf_c)::value;
+  auto tile_body = [&](const int t, auto last_c) {
     constexpr bool has_next = !decltype(last_c)::value;
-    if (has_next) dma_tile(t + 1, buf ^ 1, next_full_c);
+    const int buf = t & (NS - 1);
+    if (t + NS - 1 < nt) dma_tile(t + NS - 1, (t + NS - 1) & (NS - 1), std::false_type{});   // the stage tile t-1 has just left
     const lds_u8* kb = lds + buf * 2 * TILE_BYTES;
     const lds_u8* vb = kb + TILE_BYTES;
 
     f32x16 s0, s1, d0, d1;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) { s0[e] = sinit[e]; s1[e] = sinit[e]; d0[e] = 0.f; d1[e] = 0.f; }
+    for (int e = 0; e < 16; ++e) { s0[e] = sinit; s1[e] = sinit; d0[e] = 0.f; d1[e] = 0.f; }
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
       const int co = 16 * ((2 * ks + h) ^ kfz);
@@ -193,31 +208,16 @@ __global__ __launch_bounds__(512) void attn_bwd_dq2_kernel(const AttnBwdDq2Param
         dqacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, dsb[kk], dqacc[d], 0, 0, 0);
       }
     }
-    if (has_next) lcv_dma_wait_all();   // the next tile, requested at the top of this one, has had the whole tile to land
+    if (has_next) {   // tile t+1 is in; what was requested after it may still be in flight
+      const int later = nt - 2 - t;   // tiles requested after t+1 (at most NS - 2 of them are outstanding)
+      if (NS == 4 && later >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (NS == 4 && later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else lcv_dma_wait_all();
+    }
     __syncthreads();
   };
-  {
-    using B0 = std::integral_constant<int, 0>;
-    using B1 = std::integral_constant<int, 1>;
-    using Y = std::true_type;
-    using N = std::false_type;
-    int t = 0;
-    for (; t + 3 < nt; t += 2) {
-      tile_body(t, B0{}, N{}, Y{});
-      tile_body(t + 1, B1{}, N{}, Y{});
-    }
-    const int left = nt - t;
-    if (left == 3) {
-      tile_body(t, B0{}, N{}, Y{});
-      tile_body(t + 1, B1{}, N{}, N{});
-      tile_body(t + 2, B0{}, Y{}, N{});
-    } else if (left == 2) {
-      tile_body(t, B0{}, N{}, N{});
-      tile_body(t + 1, B1{}, Y{}, N{});
-    } else {
-      tile_body(t, B0{}, Y{}, N{});
-    }
-  }
+  for (int t = 0; t + 1 < nt; ++t) tile_body(t, std::false_type{});
+  tile_body(nt - 1, std::true_type{});   // the (possibly ragged) last tile: the only body with mask code
 
   const int64_t qrow = q0 + r;
   if (qrow < p.Nq) {
@@ -245,23 +245,27 @@ int attn_bwd_dq2_launch(const void* q, const void* k, const void* v, const void*
   p.q_sb = q_sb; p.q_sn = q_sn; p.q_sh = q_sh; p.k_sb = k_sb; p.k_sn = k_sn; p.k_sh = k_sh;
   p.v_sb = v_sb; p.v_sn = v_sn; p.v_sh = v_sh; p.o_sb = o_sb; p.o_sn = o_sn; p.o_sh = o_sh;
   p.dq_sb = dq_sb; p.dq_sn = dq_sn; p.dq_sh = dq_sh; p.scale = scale;
-  const size_t lds = 2 * 2 * 64 * 256;
+  const char* we = getenv("LCV_ATTN_BWD_DQ_WAVES");   // A/B knob: 8 = one 8-wave workgroup per CU (4 stages), 4 = two 4-wave ones
+  const int nw = ((we && we[0] == '8') || k_sn != v_sn) ? 8 : 4;
+  const size_t lds = (nw == 8 ? 4 : 2) * 2 * 64 * 256;   // NS stages of (K tile | V tile)
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)attn_bwd_dq2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    if (hipFuncSetAttribute((const void*)attn_bwd_dq2_kernel<8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * 64 * 256) != hipSuccess ||
+        hipFuncSetAttribute((const void*)attn_bwd_dq2_kernel<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 64 * 256) != hipSuccess) {
       lcv_set_error("attn_bwd: cannot raise dynamic LDS");
       return LCV_EDEVICE;
     }
     attr_set = true;
   }
-  const unsigned gx = (unsigned)((Nq + 255) / 256);
+  const unsigned gx = (unsigned)((Nq + nw * 32 - 1) / (nw * 32));
   // A/B knob LCV_ATTN_BWD_XCD=1 enables the head-per-XCD block order.  OFF by default: at the K3-TTA shapes (25 200 keys x 32
   // heads) it measured 27.06 vs 26.51 ms per layer in one process - unlike the forward, these passes are not helped by it
   const char* xe = getenv("LCV_ATTN_BWD_XCD");
   p.gx = (int)gx;
   p.xcd_remap = ((B * H) % 8 == 0 && gx >= 8 && xe && xe[0] == '1') ? 1 : 0;
   const dim3 grid = p.xcd_remap ? dim3(gx * (unsigned)(H * B)) : dim3(gx, (unsigned)H, (unsigned)B);
-  hipLaunchKernelGGL(attn_bwd_dq2_kernel, grid, dim3(512), lds, s, p);
+  if (nw == 8) hipLaunchKernelGGL((attn_bwd_dq2_kernel<8, 4>), grid, dim3(512), lds, s, p);
+  else hipLaunchKernelGGL((attn_bwd_dq2_kernel<4, 2>), grid, dim3(256), lds, s, p);
   LCV_LAUNCH_CHECK("attn_bwd_dq2");
   return LCV_OK;
 }
