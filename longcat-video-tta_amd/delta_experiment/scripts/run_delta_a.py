@@ -33,9 +33,9 @@ def main(argv=None):
     R.run_delta_method(
         args, "delta_a",
         make_wrapper=lambda dit: DeltaAWrapper(dit, adaln_tembed_dim=dit.config.adaln_tembed_dim),
-        optimize_fn=lambda w, cond, train, pe, pm, device, es: optimize_delta_a(
+        optimize_fn=lambda w, cond, train, pe, pm, device, es, tv=None: optimize_delta_a(
             w, cond, train, pe, pm, num_steps=args.delta_steps, lr=args.delta_lr, device=device, dtype=torch.bfloat16,
-            early_stopper=es),
+            early_stopper=es, train_latents_variants=tv),
         params_of=lambda w: [w.delta],
         result_extra=lambda opt: {"delta_norm": opt["delta_norm"]},
         summary_head={"delta_steps": args.delta_steps, "delta_lr": args.delta_lr, "batch_videos": args.batch_videos,

@@ -34,9 +34,9 @@ def main(argv=None):
         make_wrapper=lambda dit: DeltaBWrapper(dit, num_groups=args.num_groups, adaln_tembed_dim=dit.config.adaln_tembed_dim,
                                                hidden_size=dit.config.hidden_size, delta_target=args.delta_target,
                                                delta_dim=args.delta_dim, target_blocks=args.delta_target_blocks),
-        optimize_fn=lambda w, cond, train, pe, pm, device, es: optimize_delta_b(
+        optimize_fn=lambda w, cond, train, pe, pm, device, es, tv=None: optimize_delta_b(
             w, cond, train, pe, pm, num_steps=args.delta_steps, lr=args.delta_lr, device=device, dtype=torch.bfloat16,
-            early_stopper=es),
+            early_stopper=es, train_latents_variants=tv),
         params_of=lambda w: list(w.deltas) + ([w.delta_final] if w.delta_final is not None else []),
         result_extra=lambda opt: {"delta_norms": opt["delta_norms"]},
         summary_head={"delta_target": args.delta_target, "delta_target_blocks": args.delta_target_blocks,

@@ -29,9 +29,9 @@ def main(argv=None):
     R.run_delta_method(
         args, "delta_c",
         make_wrapper=lambda dit: DeltaCWrapper(dit, out_channels=dit.config.out_channels, delta_mode=args.delta_mode),
-        optimize_fn=lambda w, cond, train, pe, pm, device, es: optimize_delta_c(
+        optimize_fn=lambda w, cond, train, pe, pm, device, es, tv=None: optimize_delta_c(
             w, cond, train, pe, pm, num_steps=args.delta_steps, lr=args.delta_lr, device=device, dtype=torch.bfloat16,
-            early_stopper=es),
+            early_stopper=es, train_latents_variants=tv),
         params_of=lambda w: [w.delta_out],
         result_extra=lambda opt: {"delta_norm": opt["delta_norm"]},
         summary_head={"delta_mode": args.delta_mode, "delta_steps": args.delta_steps, "delta_lr": args.delta_lr},

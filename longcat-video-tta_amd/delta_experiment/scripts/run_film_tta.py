@@ -32,9 +32,9 @@ def main(argv=None):
         args, "film_adapter",
         make_wrapper=lambda dit: FiLMAdapterWrapper(dit, num_groups=args.num_groups, hidden_size=dit.config.hidden_size,
                                                     film_mode=args.film_mode),
-        optimize_fn=lambda w, cond, train, pe, pm, device, es: optimize_film_adapter(
+        optimize_fn=lambda w, cond, train, pe, pm, device, es, tv=None: optimize_film_adapter(
             w, cond, train, pe, pm, num_steps=args.film_steps, lr=args.film_lr, device=device, dtype=torch.bfloat16,
-            early_stopper=es),
+            early_stopper=es, train_latents_variants=tv),
         params_of=lambda w: list(w.corrections),
         result_extra=lambda opt: {"correction_norm": opt["correction_norm"]},
         summary_head={"film_mode": args.film_mode, "num_groups": args.num_groups, "film_steps": args.film_steps,

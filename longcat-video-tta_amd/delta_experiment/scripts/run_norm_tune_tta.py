@@ -33,9 +33,9 @@ def main(argv=None):
     R.run_delta_method(
         args, "norm_tune",
         make_wrapper=lambda dit: NormTuneForward(dit, args.norm_target, also_tune_delta=args.also_tune_delta),
-        optimize_fn=lambda w, cond, train, pe, pm, device, es: optimize_norm_params(
+        optimize_fn=lambda w, cond, train, pe, pm, device, es, tv=None: optimize_norm_params(
             w, cond, train, pe, pm, num_steps=args.norm_steps, lr=args.norm_lr, device=device, dtype=torch.bfloat16,
-            early_stopper=es),
+            early_stopper=es, train_latents_variants=tv),
         params_of=lambda w: w.tuned_params,
         result_extra=lambda opt: {k: opt[k] for k in ("norm_param_drift", "delta_norm") if k in opt},
         summary_head={"norm_target": args.norm_target, "norm_steps": args.norm_steps, "norm_lr": args.norm_lr},

@@ -105,6 +105,7 @@ def main(argv=None):
             reset_dit_weights(dit, base_state)                                          # :640 per-video reset
             blob = R.load_entry(e, args, dit, device)
             cond, train, val = split_tta_latents(blob["latents"], n_ctx_lat, args.es_holdout_fraction)
+            cond, train, variants = R.train_latents_variants_for(args, pipe, blob, e, cond, train, device)   # --aug-enabled (:699-722)
             pe, pm = blob["prompt_embeds"], blob["prompt_mask"]
             es = early_stopper if (early_stopper is not None and val is not None) else None
             if es is not None:                                                          # :724-742 (the stopper snapshots the model itself)
@@ -113,7 +114,7 @@ def main(argv=None):
             tr = finetune_full_on_conditioning(dit, cond, train, pe, pm, num_steps=args.num_steps, lr=args.learning_rate,
                                                warmup_steps=args.warmup_steps, weight_decay=args.weight_decay,
                                                max_grad_norm=args.max_grad_norm, device=device, dtype=torch.bfloat16,
-                                               early_stopper=es, optimizer_type=args.optimizer)
+                                               early_stopper=es, optimizer_type=args.optimizer, train_latents_variants=variants)
             result = {"idx": idx, "video_name": e["name"], "video_path": e["path"], "caption": blob.get("caption", ""),
                       "train_time": tr["train_time"], "es_check_time": tr.get("es_check_time", 0.0),
                       "final_loss": tr["losses"][-1] if tr["losses"] else None, "num_train_steps": len(tr["losses"]),

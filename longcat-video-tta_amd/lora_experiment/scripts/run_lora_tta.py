@@ -179,6 +179,8 @@ def main(argv=None):
             cond, train, val = split_tta_latents(blob["latents"], n_ctx_lat, args.es_holdout_fraction)
             n_tok = (cond.shape[2] + train.shape[2]) * (cond.shape[3] // 2) * (cond.shape[4] // 2)
             choose_gradient_checkpointing(dit, n_tok)
+            from tta.runner_common import train_latents_variants_for
+            cond, train, variants = train_latents_variants_for(args, pipe, blob, e, cond, train, device)   # --aug-enabled
             reset_adapters()
             es = early_stopper if (early_stopper is not None and val is not None) else None
             if es is not None:
@@ -188,12 +190,14 @@ def main(argv=None):
                                                num_steps=args.num_steps, lr=args.learning_rate,
                                                warmup_steps=args.warmup_steps, weight_decay=args.weight_decay,
                                                max_grad_norm=args.max_grad_norm, device=device, dtype=torch.bfloat16,
-                                               early_stopper=es, lora_param_fn=get_params)
+                                               early_stopper=es, lora_param_fn=get_params, train_latents_variants=variants)
             result = {"idx": idx, "video_name": e["name"], "video_path": e["path"], "caption": blob.get("caption", ""),
                       "train_time": tr["train_time"], "es_check_time": tr.get("es_check_time", 0.0),
                       "final_loss": tr["losses"][-1] if tr["losses"] else None, "num_train_steps": len(tr["losses"]),
                       "batch_size": 1, "num_neighbors": 0, "early_stopping_info": tr.get("early_stopping_info"),
                       "success": True}
+            if variants is not None:
+                result["aug_variants"] = [v["name"] for v in variants]
             gen_time = 0.0
             if not args.skip_generation:
                 from tta.runner_common import generate_continuation

@@ -1,7 +1,8 @@
 """argparse groups shared by the TTA runners — flag names and defaults of the reference
 (delta_experiment/scripts/common.py:1404-1485, 1601-1706, 2438-2450; early_stopping.py:33-51), so
 `sweep_experiment/sbatch/run_sweep.sbatch` can pass its flag set unchanged.  Flags of subsystems outside the hot path
-(CLIP gate, augmentation, caption guard, online FVD) are parsed and recorded; enabling one raises a clear error."""
+(CLIP gate, caption guard, online FVD) are parsed and recorded; enabling one raises a clear error.  Augmentation is built
+(tta/augment.py: the variants' pre-encode is row (f)1 of SURVEY §8)."""
 import argparse
 from typing import Any, Dict, List
 
@@ -24,7 +25,8 @@ def add_augmentation_args(parser):
     g.add_argument("--aug-rotate-random-max", type=float, default=15.0)
     g.add_argument("--aug-rotate-random-count", type=int, default=2)
     g.add_argument("--aug-rotate-random-step", type=float, default=1.0)
-    g.add_argument("--no-aug-rotate-zoom", action="store_true", default=False)
+    g.add_argument("--no-aug-rotate-zoom", action="store_false", dest="aug_rotate_zoom")      # common.py:1697-1703
+    parser.set_defaults(aug_rotate_zoom=True)
     g.add_argument("--aug-speed-factors", type=str, default="")
     return parser
 
@@ -123,7 +125,5 @@ def reject_out_of_scope(args):
     """Subsystems outside the hot path are parsed for CLI compatibility but cannot be switched on here."""
     if getattr(args, "clip_gate_enabled", False):
         raise NotImplementedError("the CLIP gate is outside the denoise-and-adapt hot path (SURVEY §2 #15)")
-    if getattr(args, "aug_enabled", False):
-        raise NotImplementedError("pixel-level augmentation is outside the hot path (SURVEY §2 #12)")
     if any(getattr(args, k, False) for k in ("compute_fvd", "compute_fid", "compute_vbench")):
         raise NotImplementedError("online FVD/FID/VBench evaluation is outside the hot path (SURVEY §2 #17)")

@@ -26,6 +26,7 @@ from longcat_video.pipeline_longcat_video import LongCatVideoPipeline, retrieve_
 from .flow_matching import (_get_model_config, compute_flow_matching_loss, compute_flow_matching_loss_conditioned,  # noqa: F401
                             compute_flow_matching_loss_conditioned_fixed, compute_flow_matching_loss_fixed)
 from .latent_split import estimate_tta_split_budget, split_tta_latents  # noqa: F401
+from .augment import build_augmented_latent_variants, build_augmented_pixel_variants, parse_speed_factors  # noqa: F401,E402
 
 
 def load_longcat_components(checkpoint_dir: str, device: str = "cuda", dtype: torch.dtype = torch.bfloat16,

@@ -129,6 +129,31 @@ def load_entry(entry, args, dit, device, total_frames=None):
                               "(SURVEY §8(f)); pre-encode to <data-dir>/latents/*.pt")
 
 
+def train_latents_variants_for(args, pipe, blob, entry, cond, train, device):
+    """`--aug-enabled` (run_lora_tta.py:1100-1126): pixel-level variants of the TTA clip, each encoded by the VAE and cut to the
+    training window.  Pixels come from the entry (`pixel_frames` [1, 3, T, H, W] in [-1, 1] of a pre-encoded clip); a synthetic
+    entry gets seeded random pixels AND takes its latents from their encode, so that 'orig' and the variants describe one clip
+    (returns the possibly replaced (cond, train, variants))."""
+    if not getattr(args, "aug_enabled", False):
+        return cond, train, None
+    if pipe.vae is None:
+        raise RuntimeError("--aug-enabled needs the VAE encoder (checkpoint without vae/)")
+    from tta.augment import build_train_latents_variants
+    px = blob.get("pixel_frames")
+    if px is None and entry is not None and entry.get("kind") == "synthetic":
+        H, W = {"480p": (480, 832), "720p": (720, 1280)}[args.resolution]
+        n_lat = cond.shape[2] + train.shape[2]
+        g = torch.Generator(device=device).manual_seed(entry["seed"] + 31)
+        px = torch.rand((1, 3, 1 + 4 * (n_lat - 1), H, W), generator=g, device=device) * 2 - 1
+        from tta.common import encode_video
+        lat = encode_video(pipe.vae, px.to(pipe.vae.dtype), normalize=True).to(torch.bfloat16)
+        cond, train = lat[:, :, :cond.shape[2]], lat[:, :, cond.shape[2]:n_lat]
+    if px is None:
+        raise RuntimeError(f"--aug-enabled: entry {entry.get('name') if entry else '?'} carries no `pixel_frames`")
+    variants = build_train_latents_variants(pipe.vae, torch.as_tensor(px).to(device), cond, train, args)
+    return cond, train, variants
+
+
 def continuation_cond_latents(pipe, blob, entry, args, device):
     """Clean conditioning latents of the continuation, the way the reference obtains them: the `num_cond_frames` PIXEL frames
     that end at `gen_start_frame` are VAE-encoded ON THEIR OWN (lora_experiment/scripts/run_lora_tta.py:1197-1217 ->
@@ -270,14 +295,17 @@ def run_delta_method(args, method: str, make_wrapper: Callable, optimize_fn: Cal
                 # the wrapper is called directly, so the stopper scores its whole anchor set in one batched forward
                 es.setup(model=wrapper, cond_latents=cond, val_latents=val, prompt_embeds=pe, prompt_mask=pm, device=device,
                          dtype=torch.bfloat16, video_id=e["name"])
+            cond, train, variants = train_latents_variants_for(args, pipe, blob, e, cond, train, device)
             t0 = time.time()
-            opt = optimize_fn(wrapper, cond, train, pe, pm, device, es)
+            opt = optimize_fn(wrapper, cond, train, pe, pm, device, es, variants)
             torch.cuda.synchronize()
             train_time = time.time() - t0
             result = {"idx": idx, "video_name": e["name"], "video_path": e["path"], "caption": blob.get("caption", ""),
                       "train_time": train_time, "es_check_time": opt.get("es_check_time", 0.0),
                       "final_loss": opt["losses"][-1] if opt["losses"] else None, "batch_size": 1, "num_neighbors": 0,
                       "early_stopping_info": opt.get("early_stopping_info"), "success": True}
+            if variants is not None:
+                result["aug_variants"] = [v["name"] for v in variants]
             result.update(result_extra(opt))
             gen_time = 0.0
             if not args.skip_generation:

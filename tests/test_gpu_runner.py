@@ -42,6 +42,26 @@ def test_runner_end_to_end(tmp_path):
     assert len(json.loads((out / "summary.json").read_text())["results"]) == 3
 
 
+def test_runner_with_augmentation_variants(tmp_path):
+    """`--aug-enabled` (run_lora_tta.py:1100-1126): the TTA clip's pixel variants - flip, a fixed rotation pair,
+    one random rotation, a slowed copy - are each encoded by the HIP VAE encoder, cut to the training window, and the inner
+    loop draws one per step; a `speed_2x` copy is too short for the window and is skipped (tta/augment.py)."""
+    spec = importlib.util.spec_from_file_location("run_lora_tta_amd_aug", RUNNER)
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    out = tmp_path / "run_aug"
+    argv = ["--checkpoint-dir", "synthetic:2:256:64", "--data-dir", "synthetic:2", "--output-dir", str(out),
+            "--num-cond-frames", "5", "--num-frames", "13", "--tta-total-frames", "33", "--tta-context-frames", "9",
+            "--num-steps", "4", "--num-inference-steps", "2", "--lora-rank", "4", "--lora-alpha", "8", "--skip-generation",
+            "--aug-enabled", "--aug-flip", "--aug-rotate-deg", "8", "--aug-rotate-random-count", "1", "--aug-speed-factors", "0.5,2.0"]
+    m.main(argv)
+    s = json.loads((out / "summary.json").read_text())
+    assert s["num_successful"] == 2
+    for r in s["results"]:
+        names = r["aug_variants"]
+        assert names[:4] == ["orig", "flip_h", "rotate_-8.0", "rotate_+8.0"] and names[4].startswith("rotate_rand_")
+        assert names[5:] == ["slow_2x"] and r["num_train_steps"] == 4 and r["final_loss"] == r["final_loss"]
+
+
 def test_runner_builtin_lora_path(tmp_path):
     """`--use-builtin-lora`: upstream-native LoRAModule adapters behind patched forwards, same loop and artifacts
     (config.json method `lora_tta_builtin`, run_lora_tta.py:856)."""
