@@ -58,50 +58,51 @@ def rotate_clip(pixel_frames: torch.Tensor, degrees: float, zoom: bool = False) 
     return out.to(pixel_frames.dtype).permute(1, 0, 2, 3).unsqueeze(0)
 
 
+def _random_angles(lo, hi, count, step) -> List[float]:
+    """`count` rotation angles: from the `step` grid over [lo, hi] by one `torch.randint` draw, or - step <= 0 - uniform.
+    The draw consumes the global torch RNG exactly as common.py:1280-1290 does (bounds swapped if given in reverse)."""
+    lo, hi = (0.0 if lo is None else lo), (0.0 if hi is None else hi)
+    lo, hi = min(lo, hi), max(lo, hi)
+    if step and step > 0:
+        grid = torch.arange(lo, hi + 1e-6, step)
+        grid = grid if len(grid) else torch.tensor([lo])
+        return grid[torch.randint(0, len(grid), (count,))].tolist()
+    return torch.empty(count).uniform_(lo, hi).tolist()
+
+
+def _retimed(t_len: int, factor: float, device):
+    """(name, frame indices) of a speed variant: factor > 1 keeps every round(factor)-th frame (a SHORTER clip), factor < 1
+    repeats every frame round(1 / factor) times and keeps the first t_len (common.py:1293-1312); factor 1 is no variant."""
+    if factor == 1.0:
+        return None
+    if factor > 1.0:
+        n = max(2, int(round(factor)))
+        return f"speed_{n}x", torch.arange(0, t_len, step=n, device=device)
+    n = max(2, int(round(1.0 / factor)))
+    return f"slow_{n}x", torch.arange(t_len, device=device).repeat_interleave(n)[:t_len]
+
+
 def build_augmented_pixel_variants(pixel_frames: torch.Tensor, *, enable_flip: bool = False, rotate_deg: float = 0.0,
                                    rotate_random_min: float = 5.0, rotate_random_max: float = 15.0,
                                    rotate_random_count: int = 2, rotate_random_step: float = 1.0, rotate_zoom: bool = True,
                                    speed_factors: Optional[Iterable[float]] = None) -> List[Dict[str, Any]]:
-    """Variant dicts {pixel_frames [1, C, T', H, W], name}; the first is always the original clip.  Order, names, the angle
-    draws (they consume the global torch RNG exactly as the reference does) and the speed indices follow common.py:1219-1314."""
-    variants: List[Dict[str, Any]] = [{"pixel_frames": pixel_frames, "name": "orig"}]
-    t_len = int(pixel_frames.shape[2])
+    """[{pixel_frames [1, C, T', H, W], name}, ...]: the original first, then flip, the fixed rotation pair (-deg, +deg), the
+    random rotations, the speed variants - the reference's order and names (common.py:1219-1314)."""
+    made = [("orig", pixel_frames)]
     if enable_flip:
-        variants.append({"pixel_frames": pixel_frames.flip(dims=[4]), "name": "flip_h"})
+        made.append(("flip_h", pixel_frames.flip(dims=[4])))
+    turns = []                                                          # (name, angle)
     if rotate_deg and rotate_deg > 0:
-        for deg in (-rotate_deg, rotate_deg):
-            variants.append({"pixel_frames": rotate_clip(pixel_frames, deg, zoom=rotate_zoom), "name": f"rotate_{deg:+.1f}"})
+        turns += [(f"rotate_{a:+.1f}", a) for a in (-rotate_deg, rotate_deg)]
     if rotate_random_count and rotate_random_count > 0:
-        rmin = rotate_random_min if rotate_random_min is not None else 0.0
-        rmax = rotate_random_max if rotate_random_max is not None else 0.0
-        if rmin > rmax:
-            rmin, rmax = rmax, rmin
-        if rotate_random_step and rotate_random_step > 0:
-            options = torch.arange(rmin, rmax + 1e-6, rotate_random_step)
-            if len(options) == 0:
-                options = torch.tensor([rmin])
-            angles = options[torch.randint(0, len(options), (rotate_random_count,))].tolist()
-        else:
-            angles = torch.empty(rotate_random_count).uniform_(rmin, rmax).tolist()
-        for deg in angles:
-            if abs(deg) < 1e-6:
-                continue
-            variants.append({"pixel_frames": rotate_clip(pixel_frames, float(deg), zoom=rotate_zoom),
-                             "name": f"rotate_rand_{float(deg):+.1f}"})
-    if speed_factors:
-        dev = pixel_frames.device
-        for factor in speed_factors:
-            if factor == 1.0:
-                continue
-            if factor > 1.0:       # faster: every stride-th frame (a shorter clip)
-                stride = max(2, int(round(factor)))
-                idx = torch.arange(0, t_len, step=stride, device=dev)
-                variants.append({"pixel_frames": pixel_frames[:, :, idx], "name": f"speed_{stride}x"})
-            else:                  # slower: every frame repeated, cut to the original length
-                repeat = max(2, int(round(1.0 / factor)))
-                idx = torch.arange(t_len, device=dev).repeat_interleave(repeat)[:t_len]
-                variants.append({"pixel_frames": pixel_frames[:, :, idx], "name": f"slow_{repeat}x"})
-    return variants
+        drawn = _random_angles(rotate_random_min, rotate_random_max, rotate_random_count, rotate_random_step)
+        turns += [(f"rotate_rand_{float(a):+.1f}", float(a)) for a in drawn if abs(a) >= 1e-6]
+    made += [(name, rotate_clip(pixel_frames, angle, zoom=rotate_zoom)) for name, angle in turns]
+    for factor in (speed_factors or ()):
+        spec = _retimed(int(pixel_frames.shape[2]), factor, pixel_frames.device)
+        if spec is not None:
+            made.append((spec[0], pixel_frames[:, :, spec[1]]))
+    return [{"pixel_frames": px, "name": name} for name, px in made]
 
 
 def _encode(vae, pixel_frames: torch.Tensor) -> torch.Tensor:

@@ -31,37 +31,43 @@ from .augment import build_augmented_latent_variants, build_augmented_pixel_vari
 
 def load_longcat_components(checkpoint_dir: str, device: str = "cuda", dtype: torch.dtype = torch.bfloat16,
                             cp_split_hw: Optional[list] = None) -> Dict[str, object]:
+    """{"tokenizer", "text_encoder", "vae", "scheduler", "dit", "pipe"} from `<checkpoint_dir>/<subfolder>/` - the reference's
+    five loads in its order; modules with weights land on `device`, the pipeline shares them."""
     from transformers import AutoTokenizer
     from longcat_video.modules.umt5_encoder import UMT5EncoderModel
-    if cp_split_hw is None:
-        cp_split_hw = [1, 1]
-    tokenizer = AutoTokenizer.from_pretrained(checkpoint_dir, subfolder="tokenizer")
-    text_encoder = UMT5EncoderModel.from_pretrained(checkpoint_dir, subfolder="text_encoder", torch_dtype=dtype)
-    vae = AutoencoderKLWan.from_pretrained(checkpoint_dir, subfolder="vae", torch_dtype=dtype)
-    scheduler = FlowMatchEulerDiscreteScheduler.from_pretrained(checkpoint_dir, subfolder="scheduler")
-    dit = LongCatVideoTransformer3DModel.from_pretrained(checkpoint_dir, subfolder="dit", cp_split_hw=cp_split_hw,
-                                                         enable_flashattn2=True, torch_dtype=dtype)
-    pipe = LongCatVideoPipeline(tokenizer=tokenizer, text_encoder=text_encoder, vae=vae, scheduler=scheduler, dit=dit)
-    text_encoder = text_encoder.to(device)
-    vae = vae.to(device)
-    dit = dit.to(device)
+    plan = (("tokenizer", AutoTokenizer, {}),
+            ("text_encoder", UMT5EncoderModel, {"torch_dtype": dtype}),
+            ("vae", AutoencoderKLWan, {"torch_dtype": dtype}),
+            ("scheduler", FlowMatchEulerDiscreteScheduler, {}),
+            ("dit", LongCatVideoTransformer3DModel, {"cp_split_hw": cp_split_hw or [1, 1], "enable_flashattn2": True,
+                                                     "torch_dtype": dtype}))
+    parts = {name: cls.from_pretrained(checkpoint_dir, subfolder=name, **kw) for name, cls, kw in plan}
+    pipe = LongCatVideoPipeline(**parts)
+    for name in ("text_encoder", "vae", "dit"):
+        parts[name] = parts[name].to(device)        # nn.Module.to moves in place: the pipeline's references follow
     pipe.device = torch.device(device)
-    return {"tokenizer": tokenizer, "text_encoder": text_encoder, "vae": vae, "scheduler": scheduler, "dit": dit, "pipe": pipe}
+    return dict(parts, pipe=pipe)
 
 
-def _mean_inv_std(vae, latents: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-    mean = torch.tensor(vae.config.latents_mean).view(1, vae.config.z_dim, 1, 1, 1).to(latents.device, latents.dtype)
-    inv_std = 1.0 / torch.tensor(vae.config.latents_std).view(1, vae.config.z_dim, 1, 1, 1).to(latents.device, latents.dtype)
-    return mean, inv_std
+def _latent_affine(vae, like: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Per-channel (mean, 1 / std) of the latent space as [1, z, 1, 1, 1] tensors in `like`'s dtype and device; built once per
+    (vae, device, dtype) and kept on the module - 16 scalars, but the runners normalise every clip they touch."""
+    cache = vae.__dict__.setdefault("_lcv_latent_affine", {})
+    key = (like.device, like.dtype)
+    if key not in cache:
+        shape = (1, vae.config.z_dim, 1, 1, 1)
+        mean = torch.tensor(vae.config.latents_mean).view(shape).to(*key)
+        cache[key] = (mean, 1.0 / torch.tensor(vae.config.latents_std).view(shape).to(*key))
+    return cache[key]
 
 
 def normalize_latents(vae, latents: torch.Tensor) -> torch.Tensor:
-    mean, inv_std = _mean_inv_std(vae, latents)
+    mean, inv_std = _latent_affine(vae, latents)
     return (latents - mean) * inv_std
 
 
 def denormalize_latents(vae, latents: torch.Tensor) -> torch.Tensor:
-    mean, inv_std = _mean_inv_std(vae, latents)
+    mean, inv_std = _latent_affine(vae, latents)
     return latents / inv_std + mean
 
 
@@ -95,12 +101,12 @@ def generate_video_continuation(pipe, video_frames: list, prompt: str, num_cond_
                                 num_inference_steps: int = 50, guidance_scale: float = 4.0, seed: int = 42,
                                 resolution: str = "480p", device: str = "cuda", use_kv_cache: bool = True, **embeds) -> np.ndarray:
     """list of PIL frames (or a [T,H,W,3] array) + prompt -> np.ndarray [N, H, W, 3] in [0, 1]; `**embeds` may carry
-    precomputed prompt_embeds / prompt_mask / negative_embeds / negative_mask when no text encoder is attached."""
-    vae_temporal_factor = 4
-    num_frames_valid = ((num_frames - 1 + vae_temporal_factor - 1) // vae_temporal_factor) * vae_temporal_factor + 1
-    generator = torch.Generator(device=device)
-    generator.manual_seed(seed)
-    return pipe.generate_vc(video=video_frames, prompt=prompt, resolution=resolution, num_frames=num_frames_valid,
-                            num_cond_frames=num_cond_frames, num_inference_steps=num_inference_steps,
-                            guidance_scale=guidance_scale, generator=generator, use_kv_cache=use_kv_cache,
-                            offload_kv_cache=False, **embeds)[0]
+    precomputed prompt_embeds / prompt_mask / negative_embeds / negative_mask when no text encoder is attached.  The frame
+    count is rounded up to 1 + 4k (what the causal VAE can decode) and the noise comes from a generator seeded per call."""
+    from .latent_split import num_frames_valid
+    rng = torch.Generator(device=device).manual_seed(seed)
+    clips = pipe.generate_vc(video=video_frames, prompt=prompt, resolution=resolution, num_frames=num_frames_valid(num_frames),
+                             num_cond_frames=num_cond_frames, num_inference_steps=num_inference_steps,
+                             guidance_scale=guidance_scale, generator=rng, use_kv_cache=use_kv_cache, offload_kv_cache=False,
+                             **embeds)
+    return clips[0]

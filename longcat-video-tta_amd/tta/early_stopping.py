@@ -46,12 +46,12 @@ def add_early_stopping_args(parser: argparse.ArgumentParser) -> None:
         group.add_argument(flag, **kw)
 
 
-def build_early_stopper_from_args(args) -> Optional["AnchoredEarlyStopper"]:
-    if getattr(args, "es_disable", False):
+def build_early_stopper_from_args(args):
+    """The stopper the `--es-*` flags describe, or None under `--es-disable`."""
+    if vars(args).get("es_disable"):
         return None
-    return AnchoredEarlyStopper(check_every=args.es_check_every, patience=args.es_patience,
-                                anchor_sigmas=[float(s) for s in args.es_anchor_sigmas.split(",")],
-                                noise_draws=args.es_noise_draws, strategy=args.es_strategy)
+    sigmas = list(map(float, args.es_anchor_sigmas.split(",")))
+    return AnchoredEarlyStopper(args.es_check_every, args.es_patience, sigmas, args.es_noise_draws, args.es_strategy)
 
 
 def es_seed_base(video_id: str) -> int:
@@ -127,8 +127,7 @@ class _AnchorSet:
 
 
 class AnchoredEarlyStopper:
-    def __init__(self, check_every: int = 5, patience: int = 3, anchor_sigmas: Optional[List[float]] = None,
-                 noise_draws: int = 2, strategy: str = "patience"):
+    def __init__(self, check_every=5, patience=3, anchor_sigmas=None, noise_draws=2, strategy="patience"):
         if strategy not in ("patience", "first_rise"):
             raise ValueError(f"unknown early-stopping strategy {strategy!r}")
         self.check_every, self.patience, self.strategy = check_every, patience, strategy
@@ -150,9 +149,8 @@ class AnchoredEarlyStopper:
         self.stopped_early = False
         self.loss_history: List[Tuple[int, float]] = []
 
-    def setup(self, model: nn.Module, cond_latents, val_latents, prompt_embeds, prompt_mask, device: str = "cuda",
-              dtype: torch.dtype = torch.bfloat16, forward_fn: Optional[Callable] = None, video_id: str = "",
-              save_fn: Optional[Callable] = None) -> None:
+    def setup(self, model, cond_latents, val_latents, prompt_embeds, prompt_mask, device="cuda", dtype=torch.bfloat16,
+              forward_fn=None, video_id="", save_fn=None):
         self._clear()
         self.model, self.forward_fn = model, forward_fn
         self.prompt_embeds, self.prompt_mask = prompt_embeds, prompt_mask
@@ -191,12 +189,13 @@ class AnchoredEarlyStopper:
         return self._own_snapshot.capture()
 
     # ------------------------------------------------------------------ the decision
-    def step(self, current_step: int, save_fn: Optional[Callable] = None) -> Tuple[bool, dict]:
+    def step(self, current_step, save_fn=None):
+        """(stop?, info) at a check step; (False, {}) between checks and at step 0."""
         self.step_count = current_step
-        if current_step == 0 or current_step % self.check_every:
+        if current_step % self.check_every or not current_step:
             return False, {}
         loss = self._compute_anchor_loss()
-        self.loss_history.append((current_step, loss))
+        self.loss_history += [(current_step, loss)]
         better = loss < self.best_loss
         if better:
             self.best_loss, self.best_step = loss, current_step
@@ -210,11 +209,12 @@ class AnchoredEarlyStopper:
         return stop, {"anchor_loss": loss, "best_loss": self.best_loss, "best_step": self.best_step,
                       "checks_without_improvement": self.checks_without_improvement}
 
-    def restore(self, restore_fn: Optional[Callable] = None) -> None:
+    def restore(self, restore_fn=None):
+        """Put the best snapshot back (through `restore_fn(snapshot)` when the caller owns the parameters)."""
         snap = self.best_state
         if snap is None:
             return
-        if restore_fn is not None:
+        if restore_fn:
             restore_fn(snap)
         elif isinstance(snap, ParamSnapshot):
             snap.write_back()
@@ -222,8 +222,10 @@ class AnchoredEarlyStopper:
             self.model.load_state_dict(snap, strict=False)
 
     @property
-    def state(self) -> Optional[dict]:
-        if not self.loss_history:
+    def state(self):
+        """What the runners store as `early_stopping_info` (None before the first check)."""
+        hist = self.loss_history
+        if len(hist) == 0:
             return None
-        return {"stopped_early": self.stopped_early, "best_step": self.best_step, "best_loss": self.best_loss,
-                "total_checks": len(self.loss_history), "loss_history": self.loss_history}
+        return dict(stopped_early=self.stopped_early, best_step=self.best_step, best_loss=self.best_loss, total_checks=len(hist),
+                    loss_history=hist)
