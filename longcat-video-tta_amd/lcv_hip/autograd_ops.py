@@ -335,24 +335,24 @@ class _SelfAttentionFn(torch.autograd.Function):
         want_dw = wq.requires_grad or wk.requires_grad   # norm-weight tuning (run_norm_tune_tta.py, --norm-target qk_norm)
         B, N, _, H, D = qkv.shape
         do = do.contiguous()
-        dqkv_r = torch.zeros((B, N, 3, H, D), dtype=BF16, device=qkv.device)  # grads w.r.t. roped q,k and v
-        q, k, v = qk[:, :, 0], qk[:, :, 1], qkv[:, :, 2]
-        dq, dk, dv = dqkv_r[:, :, 0], dqkv_r[:, :, 1], dqkv_r[:, :, 2]
-        if n_cond > 0:
-            ops.attention_bwd(q[:, :n_cond], k[:, :n_cond], v[:, :n_cond], o[:, :n_cond], do[:, :n_cond], lses[0],
-                              dq[:, :n_cond], dk[:, :n_cond], dv[:, :n_cond], ops.LN2, accumulate_kv=False)
-            if N > n_cond:
-                # noise queries see every key: dk/dv of the cond rows receive a second contribution
-                ops.attention_bwd(q[:, n_cond:], k, v, o[:, n_cond:], do[:, n_cond:], lses[1],
-                                  dq[:, n_cond:], dk, dv, ops.LN2, accumulate_kv=True)
-        else:
-            ops.attention_bwd(q, k, v, o, do, lses[0], dq, dk, dv, ops.LN2, accumulate_kv=False)
+        # dV needs no further transform: the kernels write it straight into the gradient of the packed qkv (strided view);
+        # dQ / dK (w.r.t. the roped, normalised q and k) go through the norm / RoPE backward below.  No zero-fill: the pass that
+        # sees EVERY key (noise queries) runs first and overwrites, the cond x cond pass then adds into the cond rows.
         dqkv = torch.empty_like(qkv)
+        dqk_r = torch.empty((B, N, 2, H, D), dtype=BF16, device=qkv.device)
+        q, k, v = qk[:, :, 0], qk[:, :, 1], qkv[:, :, 2]
+        dq, dk, dv = dqk_r[:, :, 0], dqk_r[:, :, 1], dqkv[:, :, 2]
+        if n_cond > 0 and N > n_cond:
+            ops.attention_bwd(q[:, n_cond:], k, v, o[:, n_cond:], do[:, n_cond:], lses[1],
+                              dq[:, n_cond:], dk, dv, ops.LN2, accumulate_kv=False)
+            ops.attention_bwd(q[:, :n_cond], k[:, :n_cond], v[:, :n_cond], o[:, :n_cond], do[:, :n_cond], lses[0],
+                              dq[:, :n_cond], dk[:, :n_cond], dv[:, :n_cond], ops.LN2, accumulate_kv=True)
+        else:   # no conditioning tokens, or nothing but conditioning tokens: one region
+            ops.attention_bwd(q, k, v, o, do, lses[0], dq, dk, dv, ops.LN2, accumulate_kv=False)
         dwq = torch.zeros(D, dtype=torch.float32, device=qkv.device) if want_dw else None
         dwk = torch.zeros(D, dtype=torch.float32, device=qkv.device) if want_dw else None
         ops.qknorm_rope_bwd(qkv[:, :, 0], qkv[:, :, 1], dq, dk, dqkv[:, :, 0], dqkv[:, :, 1], wq, wk, cs, 0, eps,
                             q_scale=ops.log2_qscale(scale), dwq=dwq, dwk=dwk)
-        dqkv[:, :, 2].copy_(dv)
         return (dqkv, dwq.to(wq.dtype) if (want_dw and wq.requires_grad) else None,
                 dwk.to(wk.dtype) if (want_dw and wk.requires_grad) else None, None, None, None, None)
 

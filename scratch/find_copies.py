@@ -1,5 +1,5 @@
-"""Where do the torch copy / fill / add kernels of a LoRA-TTA step come from?  torch.profiler with stacks, depth 2, 720p."""
-import sys, functools
+"""Which torch (aten) ops of a LoRA-TTA step launch GPU kernels, by self device time and shape?  torch.profiler, depth 2, 720p."""
+import sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT / "longcat-video-tta_amd")); sys.path.insert(0, str(ROOT))
@@ -18,19 +18,17 @@ cond = torch.randn(1, 16, 4, h, w, device=dev, generator=g).to(bf); train = torc
 pe = torch.randn(1, 1, 512, 4096, device=dev, generator=g).to(bf); pm = torch.zeros(1, 512, dtype=torch.int64, device=dev); pm[:, :77] = 1
 kw = dict(lr=2e-4, warmup_steps=3, device=dev, dtype=bf)
 finetune_lora_on_conditioning(dit, mods, cond, train, pe, pm, num_steps=1, **kw)
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
     finetune_lora_on_conditioning(dit, mods, cond, train, pe, pm, num_steps=1, **kw)
     torch.cuda.synchronize()
-from collections import defaultdict
-agg = defaultdict(lambda: [0, 0.0])
-for ev in prof.events():
-    if ev.name in ("aten::copy_", "aten::fill_", "aten::zero_", "aten::add", "aten::add_", "aten::contiguous", "aten::clone", "aten::_to_copy", "aten::zeros", "aten::mul", "aten::cat"):
-        dt = ev.device_time_total if hasattr(ev, "device_time_total") else ev.cuda_time_total
-        if dt <= 0:
-            continue
-        frames = [f for f in (ev.stack or []) if "longcat-video-tta_amd" in f or "/tta/" in f]
-        key = (ev.name, str(ev.input_shapes)[:60], " <- ".join(fr.split("longcat-video-tta_amd/")[-1] for fr in frames[:3]))
-        agg[key][0] += 1; agg[key][1] += dt
-rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
-for (name, shp, st), (n, t) in rows[:40]:
-    print(f"{t/1e3:8.2f} ms  x{n:4d}  {name:18s} {shp:60s} {st}")
+rows = []
+for ev in prof.key_averages(group_by_input_shape=True, group_by_stack_n=6):
+    t = getattr(ev, "self_device_time_total", 0) or getattr(ev, "self_cuda_time_total", 0)
+    if t > 0 and ev.key.startswith("aten::"):
+        st = [f for f in (ev.stack or []) if "longcat-video-tta_amd" in f or "/tta/" in f]
+        rows.append((t, ev.count, ev.key, str(ev.input_shapes)[:70], " <- ".join(s.split("longcat-video-tta_amd/")[-1][:60] for s in st[:2])))
+rows.sort(reverse=True)
+tot = sum(r[0] for r in rows)
+print(f"aten ops with GPU time: {tot/1e3:.2f} ms in total (2 blocks, 1 step)")
+for t, n, k, shp, st in rows[:30]:
+    print(f"{t/1e3:8.3f} ms x{n:4d} {k:22s} {shp:70s} {st}")
