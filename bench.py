@@ -375,7 +375,7 @@ def main():
             progress("extras 1/3: the reference's 480p operating point (generation + LoRA TTA)")
             ref_point = measure_reference_point(dit, dev, pe, pm, ne, nm)
             progress("extras 2/3: VAE decode, then 1 + 20 LoRA-TTA inner steps at the bench resolution")
-            extras = measure_extras(dit, dev, T, h, w, pe, pm)
+            extras.update(measure_extras(dit, dev, T, h, w, pe, pm))
             progress("extras 3/3: full-model TTA at the 480p operating point")
             ref_point.update(measure_full_tta_reference_point(dit, dev, pe, pm))
             progress("extras done")

@@ -86,11 +86,18 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   // LDS-DMA roles (as attn_fwd.hip): wave w fills rows 8 w .. 8 w + 7 of both tiles, 2 + 2 one-KiB instructions.  Source = a
   // scalar tile base (advanced one tile per issue by scalar adds) + a per-lane 32-bit byte offset that never changes; issued from
   // asm (lcv_common.h: a builtin DMA would be waited for before the next fragment read) and waited for at the end of the tile.
-  // (<4, 2> is launched only when K and V share their row stride - they are slices of one packed qkv tensor in the product -
-  // and then keeps ONE offset per piece: with eight the loop spilled, and a spill reload's vmcnt wait drains the DMA queue)
+  // <4, 2> keeps ONE offset per piece (with eight the loop spilled, and a spill reload's vmcnt wait drains the DMA queue): the V
+  // offset of piece i is the K offset + row_i * D, D = (v_sn - k_sn) * 2 bytes (K and V are slices of two different packed
+  // tensors in the product: strides 2 H 128 and 3 H 128); row_i = (4 NP wave + 4 i) + (lane >> 4), so the first part goes into
+  // the scalar base of the piece and the second is one more register.
   constexpr bool ONE_OFF = NW == 4;
   unsigned koff[NP], voff[ONE_OFF ? 1 : NP];
-  auto dma_row_of = [&](int i) { return 4 * NP * wave + 4 * i + (int)(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) >> 4); };
+  const int64_t kv_delta = (p.v_sn - p.k_sn) * 2;
+  auto lane16 = []() -> int { return (int)(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) >> 4); };
+  auto dma_row_of = [&](int i) { return 4 * NP * wave + 4 * i + lane16(); };
+  // recomputed from the hardware lane id at every use: a register held across the loop for it tipped three offsets into scratch
+  // (wraps for a negative delta; the SUM with koff is a true offset >= 0)
+  auto vlane = [&]() -> unsigned { return (unsigned)lane16() * (unsigned)kv_delta; };
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
     const int row = 4 * NP * wave + 4 * i + (lane >> 4);
@@ -110,7 +117,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
       for (int i = 0; i < NP; ++i) {
         lcv_lds_dma16_sv(koff[i], kt, dst + 1024u * i);
-        lcv_lds_dma16_sv(ONE_OFF ? koff[i] : voff[ONE_OFF ? 0 : i], vt, dst + (unsigned)TILE_BYTES + 1024u * i);
+        if constexpr (ONE_OFF) lcv_lds_dma16_sv(koff[i] + vlane(), vt + (4 * NP * wave + 4 * i) * kv_delta, dst + (unsigned)TILE_BYTES + 1024u * i);
+        else lcv_lds_dma16_sv(voff[i], vt, dst + (unsigned)TILE_BYTES + 1024u * i);
       }
     } else {  // ragged last tile (once per workgroup): rows past Nk re-read the last key (masked below)
 #pragma unroll
@@ -118,7 +126,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         int64_t back = (int64_t)t * 64 + dma_row_of(i) - (p.Nk - 1);
         if (back < 0) back = 0;
         lcv_lds_dma16(kt + koff[i] - back * p.k_sn * 2, dst + 1024u * i);
-        lcv_lds_dma16(vt + (ONE_OFF ? koff[i] : voff[ONE_OFF ? 0 : i]) - back * p.v_sn * 2, dst + (unsigned)TILE_BYTES + 1024u * i);
+        const int64_t vo = ONE_OFF ? (int64_t)koff[i] + (int64_t)dma_row_of(i) * kv_delta : (int64_t)voff[ONE_OFF ? 0 : i];
+        lcv_lds_dma16(vt + vo - back * p.v_sn * 2, dst + (unsigned)TILE_BYTES + 1024u * i);
       }
     }
   };
@@ -246,7 +255,7 @@ int attn_bwd_dq2_launch(const void* q, const void* k, const void* v, const void*
   p.v_sb = v_sb; p.v_sn = v_sn; p.v_sh = v_sh; p.o_sb = o_sb; p.o_sn = o_sn; p.o_sh = o_sh;
   p.dq_sb = dq_sb; p.dq_sn = dq_sn; p.dq_sh = dq_sh; p.scale = scale;
   const char* we = getenv("LCV_ATTN_BWD_DQ_WAVES");   // A/B knob: 8 = one 8-wave workgroup per CU (4 stages), 4 = two 4-wave ones
-  const int nw = ((we && we[0] == '8') || k_sn != v_sn) ? 8 : 4;
+  const int nw = (we && we[0] == '8') ? 8 : 4;
   const size_t lds = (nw == 8 ? 4 : 2) * 2 * 64 * 256;   // NS stages of (K tile | V tile)
   static bool attr_set = false;
   if (!attr_set) {

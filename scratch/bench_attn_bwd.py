@@ -7,10 +7,13 @@ dev = "cuda"; bf = torch.bfloat16
 H, D, N, nc = 32, 128, 25200, 14400
 g = torch.Generator(device=dev).manual_seed(0)
 def rmsn(t): return t * torch.rsqrt(t.float().pow(2).mean(-1, keepdim=True) + 1e-6)
-q = (rmsn(torch.randn(1, N, H, D, device=dev, generator=g)) * (D ** -0.5 * math.log2(math.e))).to(bf)
-k = rmsn(torch.randn(1, N, H, D, device=dev, generator=g)).to(bf)
-v = torch.randn(1, N, H, D, device=dev, generator=g).to(bf)
-o = torch.empty_like(q)
+# the product's layouts: q, k = slots of the roped [B, N, 2, H, D] buffer, v = slot 2 of the packed qkv GEMM output [B, N, 3, H, D]
+qk_buf = torch.empty(1, N, 2, H, D, device=dev, dtype=bf); qkv_buf = torch.empty(1, N, 3, H, D, device=dev, dtype=bf)
+qk_buf[:, :, 0] = (rmsn(torch.randn(1, N, H, D, device=dev, generator=g)) * (D ** -0.5 * math.log2(math.e))).to(bf)
+qk_buf[:, :, 1] = rmsn(torch.randn(1, N, H, D, device=dev, generator=g)).to(bf)
+qkv_buf[:, :, 2] = torch.randn(1, N, H, D, device=dev, generator=g).to(bf)
+q, k, v = qk_buf[:, :, 0], qk_buf[:, :, 1], qkv_buf[:, :, 2]
+o = torch.empty(1, N, H, D, device=dev, dtype=bf)
 _, l1 = ops.attention(q[:, :nc], k[:, :nc], v[:, :nc], math.log(2.0), out=o[:, :nc], need_lse=True)
 _, l2 = ops.attention(q[:, nc:], k, v, math.log(2.0), out=o[:, nc:], need_lse=True)
 do = torch.randn(1, N, H, D, device=dev, generator=g).to(bf)
@@ -32,7 +35,7 @@ res = {x: [] for x in vals}; outs = {}
 for rep in range(3):
     for x in vals:
         os.environ[knob] = x
-        dq = torch.zeros_like(q); dk = torch.zeros_like(k); dv = torch.zeros_like(v)
+        dq = torch.zeros(1, N, H, D, device=dev, dtype=bf); dk = torch.zeros_like(dq); dv = torch.zeros_like(dq)
         res[x].append(timeit(lambda: run(dq, dk, dv)))
         outs[x] = (dq, dk, dv)
 for x in vals:
