@@ -49,6 +49,54 @@ def test_attention_backward(B, H, Nq, Nk):
     assert rel_l2(dk2, 2 * dk.float()) < 1e-2 and rel_l2(dv2, 2 * dv.float()) < 1e-2
 
 
+@pytest.mark.parametrize("B,H,Nq,Nk", [(1, 2, 300, 300), (2, 2, 70, 333), (1, 1, 256, 128), (2, 1, 129, 64), (1, 2, 33, 5)])
+def test_attention_backward_unit_scale_forms_on_the_product_layout(B, H, Nq, Nk, monkeypatch):
+    """The second-form passes (`attn_bwd_dkv2_kernel`, `attn_bwd_dq2_kernel<4,2>` and `<8,4>`) that the self-attention of the DiT
+    takes: q pre-scaled into log2 units (scale = ln 2), q / k as slots of a [B, N, 2, H, D] buffer and v as slot 2 of a packed
+    [B, N, 3, H, D] tensor (UNEQUAL K / V row strides), gradients written into strided views, ragged last tiles, two batches;
+    asm-issued LDS-DMA with hand-placed waits, so both pass-B forms must also agree bit for bit and repeat exactly."""
+    import math
+    from lcv_hip import ops
+    D = 128
+    g = torch.Generator().manual_seed(B * 1000 + Nq)
+    qk = torch.zeros(B, max(Nq, Nk), 2, H, D, dtype=BF16)
+    qkv = torch.zeros(B, Nk, 3, H, D, dtype=BF16)
+    qs = torch.randn(B, Nq, H, D, generator=g) * 0.3
+    qk[:, :Nq, 0] = (qs * (D ** -0.5 * math.log2(math.e))).to(BF16)
+    qk[:, :Nk, 1] = (torch.randn(B, Nk, H, D, generator=g) * 0.3).to(BF16)
+    qkv[:, :, 2] = torch.randn(B, Nk, H, D, generator=g).to(BF16)
+    do = torch.randn(B, Nq, H, D, generator=g).to(BF16)
+    qk_d, qkv_d, do_d = qk.to(DEV), qkv.to(DEV), do.to(DEV)
+    q, k, v = qk_d[:, :Nq, 0], qk_d[:, :Nk, 1], qkv_d[:, :, 2]
+    o, lse = ops.attention(q, k, v, ops.LN2, need_lse=True)
+    outs = {}
+    for waves in ("4", "8"):
+        monkeypatch.setenv("LCV_ATTN_BWD_DQ_WAVES", waves)
+        dqk = torch.full((B, max(Nq, Nk), 2, H, D), 7.0, dtype=BF16, device=DEV)       # every row must be overwritten
+        dqkv = torch.full((B, Nk, 3, H, D), 7.0, dtype=BF16, device=DEV)
+        dq, dk, dv = dqk[:, :Nq, 0], dqk[:, :Nk, 1], dqkv[:, :, 2]
+        ops.attention_bwd(q, k, v, o, do_d, lse, dq, dk, dv, ops.LN2)
+        again = [t.clone() for t in (dq, dk, dv)]
+        ops.attention_bwd(q, k, v, o, do_d, lse, dq, dk, dv, ops.LN2)
+        assert all(torch.equal(a, b) for a, b in zip(again, (dq, dk, dv)))
+        assert torch.equal(dqkv[:, :, :2], torch.full_like(dqkv[:, :, :2], 7.0))           # neighbours of the strided views untouched
+        outs[waves] = [t.clone() for t in (dq, dk, dv)]
+        dk2, dv2 = dk.clone(), dv.clone()
+        ops.attention_bwd(q, k, v, o, do_d, lse, dq, dk2, dv2, ops.LN2, accumulate_kv=True)
+        assert rel_l2(dk2, 2 * dk.float()) < 1e-2 and rel_l2(dv2, 2 * dv.float()) < 1e-2
+    assert all(torch.equal(a, b) for a, b in zip(outs["4"], outs["8"]))
+    # fp32 autograd on the same bf16 inputs: softmax((q2 . k) ln 2) with q2 the pre-scaled q; dq is the gradient w.r.t. q2
+    qf = qk[:, :Nq, 0].float().permute(0, 2, 1, 3).requires_grad_(True)
+    kf = qk[:, :Nk, 1].float().permute(0, 2, 1, 3).requires_grad_(True)
+    vf = qkv[:, :, 2].float().permute(0, 2, 1, 3).requires_grad_(True)
+    ref = torch.softmax((qf @ kf.transpose(-1, -2)) * math.log(2.0), -1) @ vf
+    ref.backward(do.float().permute(0, 2, 1, 3))
+    dq, dk, dv = outs["4"]
+    assert rel_l2(dq.permute(0, 2, 1, 3), qf.grad) < 1e-2
+    assert rel_l2(dk.permute(0, 2, 1, 3), kf.grad) < 1e-2
+    assert rel_l2(dv.permute(0, 2, 1, 3), vf.grad) < 1e-2
+
+
 def test_norm_gate_swiglu_backward():
     from lcv_hip import ops
     from oracle import dit_oracle as orc
