@@ -259,10 +259,20 @@ def measure_extras(dit, dev, T, h, w, pe, pm) -> dict:
     ckpt = choose_gradient_checkpointing(dit, 7 * (h // 2) * (w // 2))
     kw = dict(lr=2e-4, warmup_steps=3, device=str(dev), dtype=torch.bfloat16)
     finetune_lora_on_conditioning(dit, mods, cond, train, pe, pm, num_steps=1, **kw)   # warm-up: builds the W^T copies
+    from lcv_hip import ops
+    ops.PROFILE_BWD = []      # HIP events around every self-attention backward of the 20 steps (the dominant kernels of this leg)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     res = finetune_lora_on_conditioning(dit, mods, cond, train, pe, pm, num_steps=20, **kw)   # BASELINE config 3: 20 iterations
     torch.cuda.synchronize()
     out["tta20_s"] = time.perf_counter() - t0          # all 20 inner steps, measured
+    prof_b, ops.PROFILE_BWD = ops.PROFILE_BWD, None
+    big = [(s.elapsed_time(e), f) for (s, e, f, nq, nk) in prof_b if nk > 512]        # self-attention regions (not the 77-key text)
+    if big:
+        ms = sum(m for m, _ in big); fl = sum(f for _, f in big)
+        out["tta_attn_bwd_roofline"] = {"kernels": "attn_bwd_delta + attn_bwd_dkv2 + attn_bwd_dq2 (two passes, no atomics)",
+                                        "bound": "mfma", "achieved": round(fl / (ms * 1e-3) / 1e12, 1), "peak": MFMA_PEAK_TFLOPS,
+                                        "unit": "TFLOP/s (algorithmic: 10 B H Nq Nk D)", "frac": round(fl / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 3),
+                                        "ms_per_layer": round(ms / (20 * len(dit.blocks)), 2), "calls": len(big)}
     out["tta_step_s"] = out["tta20_s"] / 20
     out["tta_tokens"] = 7 * (h // 2) * (w // 2)
     out["tta_block_checkpointing"] = bool(ckpt)

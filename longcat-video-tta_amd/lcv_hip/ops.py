@@ -15,6 +15,7 @@ from .lib import (LCV_EPI_GATE_RESIDUAL, LCV_EPI_GELU_TANH, LCV_EPI_NONE, LCV_EP
 BF16 = torch.bfloat16
 F32 = torch.float32
 PROFILE = None  # set to a list by bench.py to collect (start, end, flops, Nq, Nk) per attention launch
+PROFILE_BWD = None  # likewise for attention_bwd: (start, end, algorithmic flops = 10 B H Nq Nk D, Nq, Nk) per call
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -410,12 +411,18 @@ def attention_bwd(q, k, v, o, do, lse, dq, dk, dv, scale, accumulate_kv=False):
         if do.stride() != o.stride():
             raise _lib.LcvError("attention_bwd: dO must share O's strides")
     delta = torch.empty((B * H * (Nq + 2 * ((Nq + 31) // 32 * 32)),), dtype=F32, device=q.device)   # lcv_hip.h: delta_ws
+    if PROFILE_BWD is not None:   # bench.py: HIP events on the launch stream around the whole backward of this region
+        ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
+        ev0.record()
     call("lcv_attn_bwd", _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(do), _ptr(lse), _ptr(dq), _ptr(dk), _ptr(dv),
          _ptr(delta), 1 if accumulate_kv else 0, B, H, Nq, Nk,
          q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2),
          v.stride(0), v.stride(1), v.stride(2), o.stride(0), o.stride(1), o.stride(2),
          dq.stride(0), dq.stride(1), dq.stride(2), dk.stride(0), dk.stride(1), dk.stride(2),
          dv.stride(0), dv.stride(1), dv.stride(2), float(scale), _stream())
+    if PROFILE_BWD is not None:
+        ev1.record()
+        PROFILE_BWD.append((ev0, ev1, 10.0 * B * H * Nq * Nk * D, Nq, Nk))
 
 
 def swiglu_bwd(gate, up, dout):
