@@ -146,7 +146,8 @@ int lcv_attn_fwd(const void* q, const void* k, const void* v, void* o, float* ls
 const char* lcv_attn_fwd_last_kernel(void);
 /* Backward (two passes, no atomics: dK/dV per 128-key workgroup, dQ per 256-query workgroup; see csrc/attn_bwd.hip).
  * d_o shares o's strides.  delta_ws: fp32 workspace of B*H*(Nq + 2*roundup(Nq, 32)) floats (delta, then the padded
- * -lse*log2(e) / -delta rows the second-form pass A streams into LDS).  accumulate_kv != 0 adds into the existing dk/dv
+ * -lse*log2(e) / -delta rows the second-form pass A streams into LDS), plus B*H*Nk*256 floats when Nk <= 128 (fp32 partial
+ * dK / dV of a query sweep split over workgroups: the 77-key text cross-attention).  accumulate_kv != 0 adds into the existing dk/dv
  * (second region of the conditioning split).  dq/dk/dv are addressed like q/k/v with their own strides. */
 int lcv_attn_bwd(const void* q, const void* k, const void* v, const void* o,
                  const void* d_o, const float* lse,

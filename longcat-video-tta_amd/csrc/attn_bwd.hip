@@ -35,6 +35,11 @@ struct AttnBwdParams {
   int64_t dq_sb, dq_sn, dq_sh, dk_sb, dk_sn, dk_sh, dv_sb, dv_sn, dv_sh;
   float scale, scale_log2e;
   int accumulate_kv;
+  // pass A over FEW key blocks (text cross-attention: 77 keys = one block per head = 32 workgroups for 25 200 queries): the query
+  // tiles are split `qsplit` ways over workgroups, each adds its fp32 dK / dV into kv_part [B, H, Nk, 2, 128] (zeroed by the
+  // launcher), attn_bwd_kv_finish_kernel rounds (and accumulates) into dk / dv
+  int qsplit;
+  float* kv_part;
 };
 
 __device__ __forceinline__ int tile_off_b(int row, int ch) {
@@ -100,7 +105,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdParams p
   const int r = lane & 31, h = lane >> 5;
   const int head = blockIdx.y;
   const int64_t b = blockIdx.z;
-  const int64_t key0 = (int64_t)blockIdx.x * 128 + wave * 32;
+  const int qsplit = p.qsplit > 1 ? p.qsplit : 1;
+  const int kb = (int)blockIdx.x / qsplit, split = (int)blockIdx.x - kb * qsplit;
+  const int64_t key0 = (int64_t)kb * 128 + wave * 32;
 
   // ---- K, V rows of this lane's key as B operands: lane holds X[key0 + r][16*ks + 8*h .. +8] ----
   bf16x8 kf[8], vf[8];
@@ -176,12 +183,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdParams p
 #pragma unroll
     for (int e = 0; e < 16; ++e) { dkacc[d][e] = 0.f; dvacc[d][e] = 0.f; }
 
-  const int nt = (int)((p.Nq + QT - 1) / QT);
-  load_tile(0);
-  store_tile(0);
+  const int nt_all = (int)((p.Nq + QT - 1) / QT);
+  const int t_begin = (int)((int64_t)nt_all * split / qsplit), nt = (int)((int64_t)nt_all * (split + 1) / qsplit);   // this split's tiles
+  load_tile((int64_t)t_begin * QT);
+  store_tile(t_begin & 1);
   __syncthreads();
 
-  for (int t = 0; t < nt; ++t) {
+  for (int t = t_begin; t < nt; ++t) {
     const int buf = t & 1;
     const bool has_next = (t + 1 < nt);
     if (has_next) load_tile((int64_t)(t + 1) * QT);
@@ -245,6 +253,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdParams p
 
   // ---- epilogue: acc[d][e] = dX^T[dim = 32*d + (e&3) + 8*(e>>2) + 4*h][key = lane & 31] ----
   const int64_t krow = key0 + r;
+  if (p.qsplit > 1) {   // partial sums of this query range: fp32 atomics (a few MB per call), rounded by the finishing kernel
+    if (krow < p.Nk) {
+      float* part = p.kv_part + (((b * p.H + head) * p.Nk + krow) * 2) * 128;
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int col = 32 * d + 8 * i + 4 * h + e;
+            atomicAdd(part + col, dkacc[d][4 * i + e]);
+            atomicAdd(part + 128 + col, dvacc[d][4 * i + e]);
+          }
+    }
+    return;
+  }
   if (krow < p.Nk) {
     bf16_t* dkp = p.dk + b * p.dk_sb + krow * p.dk_sn + (int64_t)head * p.dk_sh;
     bf16_t* dvp = p.dv + b * p.dv_sb + krow * p.dv_sn + (int64_t)head * p.dv_sh;
@@ -269,6 +293,32 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdParams p
         *reinterpret_cast<u16x4*>(dvp + col) = pv;
       }
   }
+}
+
+// kv_part [B, H, Nk, 2, 128] fp32 -> dk / dv bf16 (strided), adding to what is there when accumulate_kv
+__global__ __launch_bounds__(256) void attn_bwd_kv_finish_kernel(const AttnBwdParams p, int64_t B) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // one thread per 4 columns of one (b, h, key, k|v) row
+  const int64_t total = B * p.H * p.Nk * 2 * 32;
+  if (i >= total) return;
+  const int c4 = (int)(i & 31);
+  const int which = (int)((i >> 5) & 1);
+  const int64_t row = i >> 6;                                   // (b * H + h) * Nk + key
+  const int64_t key = row % p.Nk, bh = row / p.Nk;
+  const int head = (int)(bh % p.H);
+  const int64_t b = bh / p.H;
+  const f32x4 v = *reinterpret_cast<const f32x4*>(p.kv_part + i * 4);
+  bf16_t* dst = which ? p.dv + b * p.dv_sb + key * p.dv_sn + (int64_t)head * p.dv_sh + 4 * c4
+                      : p.dk + b * p.dk_sb + key * p.dk_sn + (int64_t)head * p.dk_sh + 4 * c4;
+  float o[4] = {v[0], v[1], v[2], v[3]};
+  if (p.accumulate_kv) {
+    const u16x4 old = *reinterpret_cast<const u16x4*>(dst);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] += bf2f(old[e]);
+  }
+  u16x4 pk;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) pk[e] = f2bf(o[e]);
+  *reinterpret_cast<u16x4*>(dst) = pk;
 }
 
 // ---------------------------------------------------------------------------
@@ -488,9 +538,30 @@ extern "C" int lcv_attn_bwd(const void* q, const void* k, const void* v, const v
     if (rc != LCV_OK) return rc;
   } else {
     const size_t lds = 2 * (2 * 32 * 256 + 2 * 32 * 4);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)((Nk + 127) / 128), (unsigned)H, (unsigned)B), dim3(256),
-                       lds, s, p);
+    const int64_t kblocks = (Nk + 127) / 128, nt = (Nq + 31) / 32;
+    // few key blocks, many query tiles (the text cross-attention): split the query sweep so that the launch fills the chip
+    int qsplit = 1;
+    if (Nk <= 128 && kblocks * H * B < 256 && nt >= 64) {
+      qsplit = (int)(512 / (kblocks * H * B));
+      if (qsplit > nt / 16) qsplit = (int)(nt / 16);
+      if (qsplit > 64) qsplit = 64;
+    }
+    p.qsplit = qsplit;
+    p.kv_part = nullptr;
+    if (qsplit > 1) {
+      p.kv_part = delta_ws + B * H * (Nq + 2 * ((Nq + 31) / 32 * 32));      // behind the delta / row-constant rows (lcv_hip.h)
+      if (hipMemsetAsync(p.kv_part, 0, (size_t)(B * H * Nk * 256 * 4), s) != hipSuccess) {
+        lcv_set_error("attn_bwd: cannot clear the partial-sum workspace");
+        return LCV_EDEVICE;
+      }
+    }
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)(kblocks * qsplit), (unsigned)H, (unsigned)B), dim3(256), lds, s, p);
     LCV_LAUNCH_CHECK("attn_bwd_dkv");
+    if (qsplit > 1) {
+      const int64_t total = B * H * Nk * 2 * 32;
+      hipLaunchKernelGGL(attn_bwd_kv_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, B);
+      LCV_LAUNCH_CHECK("attn_bwd_kv_finish");
+    }
   }
   if (unit && (bvar & 1))
     return attn_bwd_dq2_launch(q, k, v, d_o, lse, delta_ws, dq, B, H, Nq, Nk, q_sb, q_sn, q_sh, k_sb, k_sn, k_sh, v_sb, v_sn, v_sh,

@@ -410,7 +410,8 @@ def attention_bwd(q, k, v, o, do, lse, dq, dk, dv, scale, accumulate_kv=False):
         do = do.contiguous()
         if do.stride() != o.stride():
             raise _lib.LcvError("attention_bwd: dO must share O's strides")
-    delta = torch.empty((B * H * (Nq + 2 * ((Nq + 31) // 32 * 32)),), dtype=F32, device=q.device)   # lcv_hip.h: delta_ws
+    delta = torch.empty((B * H * (Nq + 2 * ((Nq + 31) // 32 * 32) + (Nk * 256 if Nk <= 128 else 0)),), dtype=F32,
+                        device=q.device)   # lcv_hip.h: delta_ws
     if PROFILE_BWD is not None:   # bench.py: HIP events on the launch stream around the whole backward of this region
         ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
         ev0.record()

@@ -25,7 +25,8 @@ def _randn(*shape, seed=0, scale=1.0, dtype=BF16):
     return (torch.randn(*shape, generator=g) * scale).to(dtype)
 
 
-@pytest.mark.parametrize("B,H,Nq,Nk", [(1, 2, 200, 200), (2, 1, 70, 333), (1, 1, 256, 128), (1, 2, 33, 5)])
+@pytest.mark.parametrize("B,H,Nq,Nk", [(1, 2, 200, 200), (2, 1, 70, 333), (1, 1, 256, 128), (1, 2, 33, 5),
+                                       (1, 2, 4100, 77), (2, 3, 2500, 128)])      # the last two: query sweep split over workgroups
 def test_attention_backward(B, H, Nq, Nk):
     from lcv_hip import ops
     D = 128
