@@ -328,7 +328,7 @@ def test_dit_lora_gradients_match_oracle_autograd(ncond, ckpt):
     errs = [rel_l2(p.grad, l.grad) for p, l in zip(got, leaves)]
     print("max / median LoRA grad rel-L2:", max(errs), sorted(errs)[len(errs) // 2])
     print([f"{n.split('blocks.')[1]}:{e1:.3f}/{e2:.3f}" for n, e1, e2 in zip(names, errs[0::2], errs[1::2])])
-    assert max(errs) < 6e-2 and sorted(errs)[len(errs) // 2] < 3e-2
+    assert max(errs) < 3e-2 and sorted(errs)[len(errs) // 2] < 1.5e-2      # measured 1.3e-2 / 8.4e-3 (round 2)
 
 
 def test_inner_loop_matches_reference_run():
@@ -588,7 +588,7 @@ def test_full_model_gradients_match_oracle_autograd(ncond, ckpt):
     worst = sorted(errs.items(), key=lambda kv: -kv[1])[:6]
     print("params with a gradient:", len(errs), "worst:", [(k, round(v, 4)) for k, v in worst])
     vals = sorted(errs.values())
-    assert vals[-1] < 8e-2 and vals[len(vals) // 2] < 3e-2, worst
+    assert vals[-1] < 3e-2 and vals[len(vals) // 2] < 1.5e-2, worst      # measured 1.2e-2 / 7e-3 (round 2): a wrong small term would show
 
 
 def test_fused_sgd_clip_matches_torch():
