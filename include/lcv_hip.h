@@ -239,7 +239,8 @@ int lcv_unpatchify_bwd(const float* dout, float* dtok, int64_t B, int64_t Cout, 
 /* CFG-zero-star combine + sign + Euler update, fp32:
  *   st = <c,u>/(<u,u>+1e-8) per sample (computed by the callee from the partial sums in ws),
  *   v  = u*st + g*(c - u*st);  x <- x + dt * (negate ? -v : v)
- * cond/uncond: fp32 [B, n]; x: fp32 [B, n] in place; ws: fp32 [B, 2] workspace. */
+ * cond/uncond: fp32 [B, n]; x: fp32 [B, n] in place; ws: fp32 [B, 256, 2] workspace (per-slice partial sums, added in a
+ * fixed order: the step is bit-reproducible). */
 int lcv_cfg_euler_step(const float* cond, const float* uncond, float* x, float* ws,
                        int64_t B, int64_t n, float guidance, float dt, int negate,
                        int use_zero_star, void* stream);

@@ -379,9 +379,14 @@ extern "C" int lcv_unpatchify(const void* tok, float* out, int64_t B, int64_t Co
 // ---------------------------------------------------------------------------
 // Denoise-step glue (fp32 latents)
 // ---------------------------------------------------------------------------
+#define LCV_CFG_PARTS 256   // workgroups (= partial sums) per sample of the zero-star dot products
+// Partial <c, u> and <u, u> of one slice of a sample, summed in a FIXED order (lanes by the wave reduction, the four waves in
+// index order): ws[b][part][2].  No atomics: two runs of a denoise step give the same bits (a hipGraph replay of the loop is
+// compared bit for bit with the eager loop in tests/test_gpu_denoise_parity.py).
 __global__ __launch_bounds__(256) void cfg_dot_kernel(const float* __restrict__ cond,
                                                       const float* __restrict__ uncond,
                                                       float* __restrict__ ws, int64_t n) {
+  __shared__ float sd[4], sn[4];
   const int64_t b = blockIdx.y;
   const float* c = cond + b * n;
   const float* u = uncond + b * n;
@@ -393,9 +398,12 @@ __global__ __launch_bounds__(256) void cfg_dot_kernel(const float* __restrict__ 
   }
   dot = wave_sum(dot);
   nrm = wave_sum(nrm);
-  if ((threadIdx.x & 63) == 0) {
-    atomicAdd(ws + 2 * b, dot);
-    atomicAdd(ws + 2 * b + 1, nrm);
+  if ((threadIdx.x & 63) == 0) { sd[threadIdx.x >> 6] = dot; sn[threadIdx.x >> 6] = nrm; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float* o = ws + (b * LCV_CFG_PARTS + blockIdx.x) * 2;
+    o[0] = ((sd[0] + sd[1]) + sd[2]) + sd[3];
+    o[1] = ((sn[0] + sn[1]) + sn[2]) + sn[3];
   }
 }
 
@@ -404,8 +412,16 @@ __global__ __launch_bounds__(256) void cfg_euler_kernel(const float* __restrict_
                                                         float* __restrict__ x, const float* __restrict__ ws,
                                                         int64_t n, float guidance, float dt, int negate,
                                                         int use_zero_star) {
+  __shared__ float sd[4], sn[4];
   const int64_t b = blockIdx.y;
-  const float st = use_zero_star ? ws[2 * b] / (ws[2 * b + 1] + 1e-8f) : 1.0f;
+  float st = 1.0f;
+  if (use_zero_star) {   // every workgroup adds the LCV_CFG_PARTS partial sums in the same order (2 KiB from L2)
+    const float* o = ws + (b * LCV_CFG_PARTS + threadIdx.x) * 2;
+    float d = wave_sum(o[0]), q = wave_sum(o[1]);
+    if ((threadIdx.x & 63) == 0) { sd[threadIdx.x >> 6] = d; sn[threadIdx.x >> 6] = q; }
+    __syncthreads();
+    st = (((sd[0] + sd[1]) + sd[2]) + sd[3]) / ((((sn[0] + sn[1]) + sn[2]) + sn[3]) + 1e-8f);
+  }
   const float sgn = negate ? -1.0f : 1.0f;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const float c = cond[b * n + i], u = uncond[b * n + i] * st;
@@ -422,12 +438,8 @@ extern "C" int lcv_cfg_euler_step(const float* cond, const float* uncond, float*
   hipStream_t s = (hipStream_t)stream;
   int64_t bx = (n + 255) / 256;
   if (bx > 1024) bx = 1024;
-  if (use_zero_star) {
-    if (hipMemsetAsync(ws, 0, sizeof(float) * 2 * B, s) != hipSuccess) {
-      lcv_set_error("cfg_euler_step: memset failed");
-      return LCV_EDEVICE;
-    }
-    hipLaunchKernelGGL(cfg_dot_kernel, dim3((unsigned)bx, (unsigned)B), dim3(256), 0, s, cond, uncond, ws, n);
+  if (use_zero_star) {   // always LCV_CFG_PARTS workgroups per sample: every partial-sum slot is written (empty slices write 0)
+    hipLaunchKernelGGL(cfg_dot_kernel, dim3(LCV_CFG_PARTS, (unsigned)B), dim3(256), 0, s, cond, uncond, ws, n);
     LCV_LAUNCH_CHECK("cfg_dot");
   }
   hipLaunchKernelGGL(cfg_euler_kernel, dim3((unsigned)bx, (unsigned)B), dim3(256), 0, s, cond, uncond, x, ws,

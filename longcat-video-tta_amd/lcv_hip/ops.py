@@ -279,7 +279,7 @@ def cfg_euler_step(cond: torch.Tensor, uncond: torch.Tensor, x: torch.Tensor, gu
     _req(cond, F32, "cfg_euler_step.cond"); _req(uncond, F32, "cfg_euler_step.uncond"); _req(x, F32, "cfg_euler_step.x")
     B = x.shape[0]
     n = x.numel() // B
-    ws = torch.empty((B, 2), dtype=F32, device=x.device)
+    ws = torch.empty((B, 256, 2), dtype=F32, device=x.device)      # lcv_hip.h: per-slice partial sums of the zero-star dots
     call("lcv_cfg_euler_step", _ptr(cond.contiguous()), _ptr(uncond.contiguous()), _ptr(x), _ptr(ws), B, n,
          float(guidance), float(dt), 1 if negate else 0, 1 if zero_star else 0, _stream())
 

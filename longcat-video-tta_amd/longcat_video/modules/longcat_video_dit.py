@@ -38,6 +38,24 @@ class _Config(SimpleNamespace):
         return dict(self.__dict__)
 
 
+_PACK_PLANS = []   # [(weakref to the mask tensor, its _version, row indices, per-sample lengths)], newest last, at most 8
+
+
+def _pack_plan(mask: torch.Tensor):
+    """(int64 row indices into the flattened [B * L] token rows, [valid tokens per sample]) of a text mask [B, L] (or
+    [B, 1, 1, L]).  Cached per mask object + version: entries die with their tensor (a recycled address can never hit)."""
+    import weakref
+    for ref, ver, idx, lens in _PACK_PLANS:
+        if ref() is mask and ver == mask._version:
+            return idx, lens
+    m2 = mask.reshape(mask.shape[0], -1) != 0
+    idx = torch.nonzero(m2.reshape(-1), as_tuple=False).squeeze(1)
+    lens = m2.sum(dim=1).tolist()
+    _PACK_PLANS[:] = [e for e in _PACK_PLANS if e[0]() is not None][-7:]
+    _PACK_PLANS.append((weakref.ref(mask), mask._version, idx, lens))
+    return idx, lens
+
+
 class LongCatVideoTransformer3DModel(nn.Module):
     def __init__(self, device=None, dtype=torch.bfloat16, **cfg):
         super().__init__()
@@ -129,11 +147,14 @@ class LongCatVideoTransformer3DModel(nn.Module):
 
     @staticmethod
     def pack_text(encoder_hidden_states, encoder_attention_mask, hidden):
-        """Row-major masked_select packing of the valid text tokens (run_delta_a.py:180-192)."""
+        """Row-major packing of the valid text tokens (run_delta_a.py:180-192: `masked_select` by the mask).  The row indices
+        and per-sample lengths of a mask are computed once per mask OBJECT (`_pack_plan`): a 50-step denoise hands the same
+        mask to every forward, and `masked_select` + `.tolist()` would be a device -> host sync in each of them (and would
+        keep the step out of a hipGraph)."""
         if encoder_attention_mask is not None:
-            mask = encoder_attention_mask.squeeze(1).squeeze(1)
-            y = (encoder_hidden_states.squeeze(1).masked_select(mask.unsqueeze(-1) != 0).view(1, -1, hidden))
-            return y, mask.sum(dim=1).tolist()
+            idx, y_seqlens = _pack_plan(encoder_attention_mask)
+            y = encoder_hidden_states.squeeze(1).reshape(-1, hidden).index_select(0, idx).view(1, -1, hidden)
+            return y, y_seqlens
         y_seqlens = [encoder_hidden_states.shape[2]] * encoder_hidden_states.shape[0]
         return encoder_hidden_states.squeeze(1).reshape(1, -1, hidden), y_seqlens
 
@@ -206,7 +227,7 @@ class LongCatVideoTransformer3DModel(nn.Module):
         y = self.y_embedder(encoder_hidden_states)
         if self.text_tokens_zero_pad and encoder_attention_mask is not None:
             y = y * encoder_attention_mask[:, None, :, None].to(y.dtype)
-            encoder_attention_mask = (encoder_attention_mask * 0 + 1).to(encoder_attention_mask.dtype)
+            encoder_attention_mask = None        # every (zeroed) token stays in the sequence: the all-ones mask of the reference
         y, y_seqlens = self.pack_text(y, encoder_attention_mask, x.shape[-1])
 
         kv_out = {} if return_kv else None

@@ -15,6 +15,8 @@ the scheduler step (SURVEY §8(c) open question — exposed as `negate_pred`).
 """
 from typing import List, Optional, Tuple
 
+import os
+
 import numpy as np
 import torch
 
@@ -121,20 +123,47 @@ class LongCatVideoPipeline:
         Bm = emb.shape[0]
         T_in = work.shape[2]
         stop = len(timesteps) if stop_step is None else stop_step
+        # hipGraph replay of the DiT forward (opt-in: LCV_DENOISE_GRAPH=1, or automatically for launch-bound steps of at most
+        # LCV_DENOISE_GRAPH_TOKENS tokens, default 0 = never): the ~1 100 launches of a forward are captured once, after one
+        # eager step has built every cache and set every kernel attribute, and replayed with the step's latents and timestep
+        # copied into static buffers.  The fused CFG + Euler update stays outside (its step size is a host scalar).  At 1 280
+        # tokens (K1) the eager step is launch-bound; at 46 800 the launches are 0.2 % of the step and the graph is not used.
+        graph = None
+        n_tok = Bm * T_in * (work.shape[3] // 2) * (work.shape[4] // 2)
+        want_graph = (os.environ.get("LCV_DENOISE_GRAPH") == "1" or n_tok <= int(os.environ.get("LCV_DENOISE_GRAPH_TOKENS", "0"))) \
+            and not torch.is_grad_enabled() and getattr(dit, "_sp_group", None) is None and stop - start_step >= 3
+
+        def forward(x_in, ts):
+            if kv is not None:
+                return dit(hidden_states=x_in, timestep=ts, encoder_hidden_states=emb, encoder_attention_mask=mask,
+                           num_cond_latents=ncl, kv_cache_dict=kv)
+            return dit(hidden_states=x_in, timestep=ts, encoder_hidden_states=emb, encoder_attention_mask=mask,
+                       num_cond_latents=ncl)
+        x_static = ts_static = pred_static = None
         for i in range(start_step, stop):
             t = timesteps[i]
-            x_in = work.to(torch.bfloat16)
-            if do_cfg:
-                x_in = x_in.expand(2, -1, -1, -1, -1)
-            ts = torch.full((Bm, T_in), t, device=dev, dtype=torch.bfloat16)
-            if kv is None and ncl > 0:
-                ts[:, :ncl] = 0
-            if kv is not None:
-                pred = dit(hidden_states=x_in, timestep=ts, encoder_hidden_states=emb, encoder_attention_mask=mask,
-                           num_cond_latents=ncl, kv_cache_dict=kv)
+            if graph is not None:
+                x_static.copy_(work.expand_as(x_static) if do_cfg else work)       # fp32 -> bf16 into the captured input
+                ts_static.fill_(t)
+                if kv is None and ncl > 0:
+                    ts_static[:, :ncl] = 0
+                graph.replay()
+                pred = pred_static
             else:
-                pred = dit(hidden_states=x_in, timestep=ts, encoder_hidden_states=emb, encoder_attention_mask=mask,
-                           num_cond_latents=ncl)
+                x_in = work.to(torch.bfloat16)
+                if do_cfg:
+                    x_in = x_in.expand(2, -1, -1, -1, -1)
+                ts = torch.full((Bm, T_in), t, device=dev, dtype=torch.bfloat16)
+                if kv is None and ncl > 0:
+                    ts[:, :ncl] = 0
+                pred = forward(x_in, ts)
+                if want_graph and i == start_step:      # the eager step above was the warm-up: capture for the remaining steps
+                    x_static = x_in.contiguous().clone()
+                    ts_static = ts.clone()
+                    torch.cuda.synchronize()
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):
+                        pred_static = forward(x_static, ts_static)
             dt = sched.dt(i)
             if kv is None and ncl > 0:
                 tgt = work[:, :, ncl:]

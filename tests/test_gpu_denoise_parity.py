@@ -120,6 +120,37 @@ def test_k1_denoise_matches_cpu_oracle_every_step(dit2, ncond, use_kv, steps):
     assert upd < 1.5e-2, upd
 
 
+@pytest.mark.parametrize("ncond,use_kv", [(0, True), (2, True), (2, False)])
+def test_graph_replayed_denoise_equals_the_eager_loop(dit2, ncond, use_kv, monkeypatch):
+    """LCV_DENOISE_GRAPH=1: the DiT forward of a denoise step is captured into a hipGraph after the first (eager) step and
+    replayed with the step's latents / timestep copied into static buffers.  Same kernels, same order, same buffers' contents:
+    the latents after every step must equal the eager loop's bit for bit (K1 shape, full width, CFG, all three
+    conditioning forms).  Also prints the step times: at 1 280 tokens the eager step is launch-bound."""
+    import time
+    pipe = _pipe(dit2)
+    lat = torch.randn(1, 16, 5, 32, 32, generator=torch.Generator().manual_seed(7)).to(DEV)
+    pe, pm, ne, nm = (t.to(DEV) for t in _text())
+
+    def run(flag, steps=8):
+        monkeypatch.setenv("LCV_DENOISE_GRAPH", flag)
+        seen = []
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        with torch.no_grad():
+            out = pipe.denoise(lat, pe, pm, ne, nm, num_cond_latents=ncond, num_inference_steps=steps, guidance_scale=4.0,
+                               use_kv_cache=use_kv, step_callback=lambda i, x: seen.append(x.clone()))
+        torch.cuda.synchronize()
+        return out, seen, (time.perf_counter() - t0) / steps
+    run("0", 3)                                            # warm-up of both code paths' caches
+    eager, seen_e, t_e = run("0")
+    graph, seen_g, t_g = run("1")
+    assert len(seen_e) == len(seen_g) == 8
+    for i, (a, b) in enumerate(zip(seen_e, seen_g)):
+        assert torch.equal(a, b), f"step {i}"
+    assert torch.equal(eager, graph)
+    print(f"K1 depth 2, ncond={ncond} kv={use_kv}: eager {t_e * 1e3:.2f} ms / step, graph (incl. capture) {t_g * 1e3:.2f} ms / step")
+    _record(f"graph_k1_ncond{ncond}_kv{int(use_kv)}", {"eager_ms_per_step": t_e * 1e3, "graph_ms_per_step_incl_capture": t_g * 1e3})
+
+
 def test_oracle_is_device_independent(dit2):
     """The oracle evaluated with torch fp32 ops on the card equals the oracle on host cores up to summation order: this is
     what lets the K2 / K3 tests below use it at sizes the host cannot finish."""
