@@ -969,6 +969,30 @@ static int launch_gemm8p(GemmParams& p, hipStream_t s) {
 }
 
 #include "gemm4w.h"
+#include "gemm4p.h"
+
+// two-phase form of the 8-phase kernel (gemm4p.h), persistent; thin tails are left unsplit (A/B knob LCV_GEMM_TILE=3)
+template <int EPI>
+static int launch_gemm4p(GemmParams& p, hipStream_t s) {
+  p.tiles_m = (int)((p.M + 255) / 256);
+  { const char* ge = getenv("LCV_GEMM_GROUP_M"); p.group_m = ge ? atoi(ge) : 6; if (p.group_m < 1) p.group_m = 6; }
+  p.tiles_n = (int)((p.N + 255) / 256);
+  const size_t lds = 2 * 65536;
+  auto kern = gemm4p_nt_kernel<EPI, true>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      lcv_set_error("gemm_nt: cannot raise dynamic LDS to %zu", lds);
+      return LCV_EDEVICE;
+    }
+    attr_set = true;
+  }
+  const int ntiles = p.tiles_m * p.tiles_n;
+  p.vid_begin = 0; p.vid_count = ntiles; p.splitk = 1; p.nk_split = 0; p.ws = nullptr;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(ntiles > 256 ? 256 : ntiles)), dim3(512), lds, s, p);
+  LCV_LAUNCH_CHECK("gemm4p_nt");
+  return LCV_OK;
+}
 
 // four waves x 128 x 128 (gemm4w.h), persistent over all tiles of the launch
 template <int EPI, int NW>
@@ -1047,6 +1071,7 @@ static int dispatch_tile(GemmParams& p, hipStream_t s) {
                    (p.nk2 == 0 || ((uint64_t)p.M * p.lda2 * 2 < (1ull << 32) && (uint64_t)p.N * p.ldw2 * 2 < (1ull << 32)));
   if (mode == 6 && ok8) mode = 9;  // persistent workgroups (identical to 8 when there are no more tiles than CUs)
   if (force) mode = force[0] - '0';
+  if (mode == 3 && ok8) return launch_gemm4p<EPI>(p, s);
   if (mode == 4 && ok8) return launch_gemm4w<EPI, 4>(p, s);
   if (mode == 5 && ok8) return launch_gemm4w<EPI, 8>(p, s);
   if (mode == 8 && ok8) return launch_gemm8p<EPI, false>(p, s);
