@@ -277,6 +277,22 @@ def measure_extras(dit, dev, T, h, w, pe, pm) -> dict:
     out["tta_tokens"] = 7 * (h // 2) * (w // 2)
     out["tta_block_checkpointing"] = bool(ckpt)
     out["tta_losses"] = [round(x, 4) for x in res["losses"][:2]] + ["..."] + [round(res["losses"][-1], 4)]
+    # the same 20 steps WITH the anchored early stopper ("a second run ES on"): 1 held-out latent frame, 3 sigmas x 2
+    # noise draws scored as one resident batch at setup and every 5 steps (patience 3: a synthetic loss keeps falling, so all
+    # 20 steps and all 5 checks run)
+    from tta.early_stopping import AnchoredEarlyStopper
+    from tta.lora import reset_lora_weights
+    reset_lora_weights(mods)
+    val = torch.randn((1, 16, 1, h, w), generator=g, device=dev).to(torch.bfloat16)
+    es = AnchoredEarlyStopper(check_every=5, patience=3)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    es.setup(dit, cond, val, pe, pm, device=str(dev), dtype=torch.bfloat16, video_id="bench")
+    res_es = finetune_lora_on_conditioning(dit, mods, cond, train, pe, pm, num_steps=20, early_stopper=es, **kw)
+    torch.cuda.synchronize()
+    out["tta20_es_s"] = time.perf_counter() - t0
+    out["tta20_es_steps_run"] = len(res_es["losses"])
+    out["tta20_es_check_time_s"] = round(res_es.get("es_check_time", 0.0), 2)
+    out["tta20_es_checks"] = (res_es.get("early_stopping_info") or {}).get("total_checks")
     remove_lora_from_dit(dit)
     return out
 
@@ -384,7 +400,7 @@ def main():
         with contextlib.redirect_stdout(sys.stderr):   # stdout carries exactly one JSON line
             progress("extras 1/3: the reference's 480p operating point (generation + LoRA TTA)")
             ref_point = measure_reference_point(dit, dev, pe, pm, ne, nm)
-            progress("extras 2/3: VAE decode, then 1 + 20 LoRA-TTA inner steps at the bench resolution")
+            progress("extras 2/3: VAE decode, then 1 + 20 LoRA-TTA inner steps at the bench resolution, then 20 more with early stopping")
             extras.update(measure_extras(dit, dev, T, h, w, pe, pm))
             progress("extras 3/3: full-model TTA at the 480p operating point")
             ref_point.update(measure_full_tta_reference_point(dit, dev, pe, pm))
