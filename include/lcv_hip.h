@@ -312,13 +312,17 @@ int lcv_gelu_tanh_bwd(const void* x, const void* dy, void* dx, int64_t n, void* 
 
 /* ---- VAE stages (WAN-style causal 3-D conv VAE; upstream AutoencoderKLWan.decode / .encode, contract at
  * delta_experiment/scripts/common.py:209-221) --------------------------------------------------------------- */
-/* Causal conv3d as an implicit GEMM on the MFMA core.  x [B,Tin,Hin,Win,Cin] channels-last bf16 (Cin % 64 == 0,
- * padded channels zero); w [Cout, kt*kh*kw*Cin] with K ordered (dt,dh,dw,cin); out [B,T,H,W,ldc], (H,W) doubled when
+/* Causal conv3d as an implicit GEMM on the MFMA core.  x [B,Tin,Hin,Win,ldx] channels-last bf16 with Cin % 32 == 0 valid
+ * channels and pixel stride ldx = Cin rounded up to a multiple of 64 (padding channels zero, in x and in w - a caller may as
+ * well pass Cin = ldx); w [Cout, kt*kh*kw*ldx] with K ordered (dt,dh,dw,cin); out [B,T,H,W,ldc], (H,W) doubled when
  * up2x (nearest upsample folded into the gather).  kt-1 zero frames of causal padding in front, zero spatial padding.
  * resid (nullable, laid out like out): out = resid + bf16(conv + bias).  zero_page: >= 128 bytes of device zeros. */
 int lcv_causal_conv3d(const void* x, const void* w, const void* bias, const void* resid, void* out,
                       const void* zero_page, int64_t B, int64_t Tin, int64_t Hin, int64_t Win, int64_t Cin,
                       int64_t Cout, int64_t ldc, int kt, int kh, int kw, int up2x, void* stream);
+/* Which kernel the most recent lcv_causal_conv3d / lcv_conv3d_strided call of this thread launched (static string, "none"
+ * before the first call): the row-tile kernel for the 96-channel stages or the implicit GEMM (csrc/conv_rows.h). */
+const char* lcv_conv3d_last_kernel(void);
 /* Strided conv3d for the VAE ENCODER's downsampling stages (upstream WanResample "downsample2d/3d": ZeroPad2d((0,1,0,1))
  * + 3x3 stride-2 conv per frame; (3,1,1) stride-2 temporal conv over [cached last frame | chunk]; contract of
  * vae.encode at delta_experiment/scripts/common.py:158-174).  Output pixel (t,h,w) reads input (t*st+dt, h*sh+dh, w*sw+dw),

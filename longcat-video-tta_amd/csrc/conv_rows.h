@@ -1,0 +1,287 @@
+// Row-tile convolution for the VAE's 96-channel stages (included by gemm.hip: GemmParams, gemm16_epilogue, f32x4v, bf16x8).
+//
+// Why a second convolution kernel.  The implicit-GEMM form above stages, for every tap, the 128 or 256 gathered input rows of
+// its output tile: at 96 channels (the 720p stage of the decoder, the first stage of the encoder) that is a 128 x 128 tile
+// padded from 96 x 96 - 44 % of the MFMA work multiplies zeros - and 32 KB of L2->LDS traffic per 1.2 real MFLOP.  Counters
+// (profiles/r03_conv_pmc.md): MFMA busy 0.32, HBM 0.7 TB/s, L2 hit 0.92, 11.4 TB/s of LDS-DMA fill - the kernel is bound by the
+// L2->LDS path (guide: 17-19 TB/s from L2 at best), not by the matrix pipe, HBM or address arithmetic.
+//
+// This kernel cuts that traffic 3.6x and drops the padding:
+//   * an output tile is 256 consecutive pixels of ONE image row (b, t, h, w0 .. w0+255), all Cout <= 96 channels;
+//   * a step is one (dt, dh, 96-channel slice): the input row segment [w0 - pw, w0 + 256 + kw - 1 - pw) is staged ONCE
+//     (258 pixels x 96 channels) and serves the kw taps of that row - tap dw of output pixel r reads staged pixel r + dw;
+//     row / frame validity of a step is uniform over the tile (skipped steps are never staged), column validity is a
+//     per-lane property of the staging (zero page), so the K loop carries no per-pixel masks at all;
+//   * the weights of one tap (Cout x 96) are staged per tap, in three buffers beside the double-buffered pixel segment;
+//   * with the folded 2x upsample the segment is staged in UPSAMPLED coordinates (pixel u reads source u >> 1).
+//
+// LDS image.  The fragment of lane (r16, q) for K block kk is 16 bytes; a tap reads the same image at a row offset dw, so the
+// image must be conflict-free for ds_read_b128 under ANY row shift.  An XOR swizzle is not (it is tied to row mod 16), and a
+// padded row stride cannot be (the four 16-lane groups of ds_read_b128 mix rows {0-3, 12-15} of q with rows {4-11} of q + 1).
+// What is: one plane per q, rows 48 bytes apart, plane size a multiple of 256 bytes -
+//     addr(row, q, kk) = q * PLANE + row * 48 + kk * 16
+// The bank unit (addr / 16) mod 16 = (3 row + kk) mod 16 takes 16 different values over the 16 rows of a lane group whatever
+// the shift, because 3 is odd and the plane offset drops out.  The 48 bytes of a plane row are channels [24 q, 24 q + 24): the
+// MFMA K index is permuted (k = 8 (l >> 4) + e of block kk  <->  channel 24 q + 8 kk + e) identically for both operands, which
+// changes only the order of the fp32 sums.  LDS-DMA fills the planes linearly: lane l of piece g writes unit 64 g + l, i.e. row
+// (64 g + l) / 3, block (64 g + l) % 3, and fetches those 16 bytes from global memory.
+#pragma once
+
+template <int WM, int WN, int TM, int TN>
+struct ConvRowsCfg {
+  static constexpr int BM = WM * TM * 16;           // 256 output pixels
+  static constexpr int BN = WN * TN * 16;           // 96 (or 16: the 3-channel head)
+  static constexpr int NW = WM * WN;                // 8 waves
+  static constexpr int A_PIECES_PER_PLANE = 13;     // 13 KiB >= (256 + 2) rows x 48 B, and 13312 % 256 == 0
+  static constexpr int PLA = A_PIECES_PER_PLANE * 1024;
+  static constexpr int A_BYTES = 4 * PLA;           // 53248
+  static constexpr int A_PIECES = 4 * A_PIECES_PER_PLANE;
+  static constexpr int PLB = BN * 48;               // 4608 / 768: both multiples of 256
+  static constexpr int B_BYTES = 4 * PLB;
+  static constexpr int B_PIECES = B_BYTES / 1024;   // 18 / 3
+  static constexpr int IA = (A_PIECES + NW - 1) / NW;   // 7 piece slots per wave (the last one half used)
+  static constexpr int IB = (B_PIECES + NW - 1) / NW;   // 3 / 1
+  static constexpr int LDS_BYTES = 2 * A_BYTES + 3 * B_BYTES;   // 161792 of 163840
+  static_assert(BM == 256 && NW == 8, "conv_rows: 256-pixel tiles, 8 waves");
+  static_assert(PLB % 256 == 0 && B_BYTES % 1024 == 0, "conv_rows: weight planes must keep the bank phase");
+};
+
+template <int WM, int WN, int TM, int TN, int EPI>
+__global__ __launch_bounds__(512) void conv_rows_kernel(const GemmParams p, const int tiles_per_row, const int n_tiles) {
+  using Cfg = ConvRowsCfg<WM, WN, TM, TN>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int r16 = lane & 15, q = lane >> 4;
+
+  // workgroup -> tile: ids that share an XCD (id % 8) walk one contiguous run of tiles, i.e. a band of image rows whose
+  // dh / dt neighbours stay in that XCD's L2
+  int pid;
+  {
+    const int orig = (int)blockIdx.x, xcd = orig & 7;
+    const int per = n_tiles >> 3, r8 = n_tiles & 7;
+    pid = (xcd < r8 ? xcd * (per + 1) : r8 * (per + 1) + (xcd - r8) * per) + (orig >> 3);
+  }
+  const int wt = pid % tiles_per_row;
+  int rowid = pid / tiles_per_row;
+  const int ho = rowid % p.cv_H; rowid /= p.cv_H;
+  const int to = rowid % p.cv_T;
+  const int bb = rowid / p.cv_T;
+  const int w0 = wt * Cfg::BM;
+  const int up = p.cv_up2x ? 1 : 0;
+  const int ldx = (int)p.lda;                                   // pixel stride of x in elements
+  const int ncs = p.cv_cpt;                                     // 96-channel slices per tap
+
+  // the (dt, dh) taps that read inside the tensor: ranges, since padding is in front (t) or symmetric (h) and stride is 1
+  const int t0 = to - p.cv_pt, h0 = ho - p.cv_ph;
+  const int hb = p.cv_Hin << up;
+  const int dt_lo = t0 < 0 ? -t0 : 0, dt_hi = (p.cv_Tin - t0) < p.cv_kt ? (p.cv_Tin - t0) : p.cv_kt;   // [lo, hi)
+  const int dh_lo = h0 < 0 ? -h0 : 0, dh_hi = (hb - h0) < p.cv_kh ? (hb - h0) : p.cv_kh;
+  const int ndh = dh_hi - dh_lo;
+  const int nsteps = (dt_hi - dt_lo) * ndh * ncs;
+  const int kw = p.cv_kw;
+  const int nsub = nsteps * kw;
+
+  // ---- staging plans (per lane, once per tile) ----
+  // pixel segment: piece slot t of this wave is piece g = 8 t + wave; unit (g % 13) * 64 + lane of plane g / 13
+  unsigned a_off[Cfg::IA];
+  const int wbound = p.cv_Win << up;
+#pragma unroll
+  for (int t = 0; t < Cfg::IA; ++t) {
+    const int g = t * Cfg::NW + wave;
+    const int plane = g / Cfg::A_PIECES_PER_PLANE;
+    const int u = (g - plane * Cfg::A_PIECES_PER_PLANE) * 64 + lane;
+    const int row = u / 3, kk = u - row * 3;
+    const int uu = w0 - p.cv_pw + row;                           // (upsampled) input column of staged row `row`
+    const bool ok = g < Cfg::A_PIECES && row < Cfg::BM + kw - 1 && uu >= 0 && uu < wbound;
+    a_off[t] = ok ? (unsigned)(((uu >> up) * ldx + plane * 24 + kk * 8) * 2) : 0xFFFFFFFFu;
+  }
+  // weights of one tap: piece g = 8 t + wave; unit 64 g + lane -> plane, output channel n, block kk
+  unsigned b_off[Cfg::IB];
+#pragma unroll
+  for (int t = 0; t < Cfg::IB; ++t) {
+    const int g = t * Cfg::NW + wave;
+    const int u = g * 64 + lane;
+    const int plane = u / (Cfg::BN * 3);
+    const int rem = u - plane * (Cfg::BN * 3);
+    int n = rem / 3;
+    const int kk = rem - n * 3;
+    if (n > (int)p.N - 1) n = (int)p.N - 1;                      // rows past Cout: any finite data, masked by the epilogue
+    b_off[t] = (unsigned)((n * (int)p.ldw + plane * 24 + kk * 8) * 2);
+  }
+  const uint64_t zpage = (uint64_t)p.cv_zero + (unsigned)(lane & 7) * 16u;
+
+  // step -> (dt, dh, slice): scalar
+  auto step_coords = [&](int step, int& dt, int& dh, int& cs) {
+    cs = step % ncs;
+    const int r = step / ncs;
+    dh = dh_lo + r % ndh;
+    dt = dt_lo + r / ndh;
+  };
+  auto stage_pixels = [&](int step, int t_begin, int t_end) {
+    int dt, dh, cs;
+    step_coords(step, dt, dh, cs);
+    const int64_t in_row = ((int64_t)(bb * p.cv_Tin + t0 + dt) * p.cv_Hin + ((h0 + dh) >> up)) * p.cv_Win;
+    const uint64_t base = (uint64_t)(p.a + in_row * ldx + cs * 96);
+    unsigned char* dst = smem + (step & 1) * Cfg::A_BYTES;
+#pragma unroll
+    for (int t = 0; t < Cfg::IA; ++t) {
+      if (t < t_begin || t >= t_end) continue;
+      const int g = t * Cfg::NW + wave;
+      if (g >= Cfg::A_PIECES) continue;                          // wave-uniform
+      const bool ok = a_off[t] != 0xFFFFFFFFu;
+      const uint64_t src = ok ? base + a_off[t] : zpage;
+      __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(dst + g * 1024), 16, 0, 0);
+    }
+  };
+  auto stage_weights = [&](int sub) {
+    const int step = sub / kw, dw = sub - step * kw;
+    int dt, dh, cs;
+    step_coords(step, dt, dh, cs);
+    const int tap = (dt * p.cv_kh + dh) * kw + dw;
+    const uint64_t base = (uint64_t)(p.w + (int64_t)tap * ldx + cs * 96);
+    unsigned char* dst = smem + 2 * Cfg::A_BYTES + (sub % 3) * Cfg::B_BYTES;
+#pragma unroll
+    for (int t = 0; t < Cfg::IB; ++t) {
+      const int g = t * Cfg::NW + wave;
+      if (g >= Cfg::B_PIECES) continue;                          // wave-uniform
+      __builtin_amdgcn_global_load_lds((gbl_void*)(base + b_off[t]), (lds_void*)(dst + g * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x4v acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+  const int a_frag = q * Cfg::PLA + (wm * TM * 16 + r16) * 48;
+  const int b_frag = q * Cfg::PLB + (wn * TN * 16 + r16) * 48;
+
+  // ---- pipeline: loads run TWO sub-steps ahead of the MFMAs ----
+  // One workgroup owns the CU (143-162 KB of LDS), so nothing else hides a DMA round trip: with the next sub-step's images
+  // requested only one sub-step ahead, a sub-step took ~1.9 us against 0.5 us of MFMA work - the latency of a loaded L2, not
+  // its bandwidth (35 KB per sub-step and CU).  Weights of sub-step j + 2 and the next pixel segment (its pieces spread over
+  // the first two taps of the current step) are requested at sub-step j, into a third weight buffer; the wait at the top of a
+  // sub-step is counted: this wave's requests of the previous sub-step may stay in flight, except a segment part that
+  // completes the segment the coming sub-step starts on (those were issued before the weights, so they are the older ones).
+  int nb_wave = 0;
+#pragma unroll
+  for (int t = 0; t < Cfg::IB; ++t) nb_wave += (t * Cfg::NW + wave < Cfg::B_PIECES) ? 1 : 0;
+  auto na_wave = [&](int t_begin, int t_end) {
+    int n = 0;
+#pragma unroll
+    for (int t = 0; t < Cfg::IA; ++t) n += (t >= t_begin && t < t_end && t * Cfg::NW + wave < Cfg::A_PIECES) ? 1 : 0;
+    return n;
+  };
+  auto part_begin = [&](int dw) { return kw >= 3 ? (dw == 0 ? 0 : dw == 1 ? 4 : Cfg::IA) : (dw == 0 ? 0 : Cfg::IA); };
+  auto part_end = [&](int dw) { return kw >= 3 ? (dw == 0 ? 4 : Cfg::IA) : Cfg::IA; };
+  auto wait_allow = [&](int n) {       // s_waitcnt takes an immediate
+    switch (n) {
+      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+      case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    }
+  };
+
+  const int lab = p.splitk;   // scratch/pmc_conv.py only (LCV_CONV_LAB): 1 = no staging inside the loop, 2 = no MFMAs, 4 = no epilogue, 8 = all waves request first
+  const bool late = wave >= 4 && !(lab & 8);
+  int allow = 0;
+  if (nsub > 0) {
+    stage_pixels(0, 0, Cfg::IA);
+    stage_weights(0);
+    if (nsub > 1) { stage_weights(1); allow = nb_wave; }
+  }
+  for (int sub = 0; sub < nsub; ++sub) {
+    const int step = sub / kw, dw = sub - step * kw;
+    wait_allow(allow);                                           // this sub-step's images have landed (this wave's part)
+    __builtin_amdgcn_s_barrier();                                // ... everyone's; and all waves are done with sub-step sub - 1
+    int issued = 0, a_issued = 0;
+    auto request = [&]() {
+      if (lab & 1) return;
+      if (step + 1 < nsteps) {                                   // segment of the next step (older than the weights below)
+        stage_pixels(step + 1, part_begin(dw), part_end(dw));
+        a_issued = na_wave(part_begin(dw), part_end(dw));
+        issued += a_issued;
+      }
+      if (sub + 2 < nsub) { stage_weights(sub + 2); issued += nb_wave; }
+    };
+    auto multiply = [&]() {
+      const unsigned char* sa = smem + (step & 1) * Cfg::A_BYTES + a_frag + dw * 48;
+      const unsigned char* sb = smem + 2 * Cfg::A_BYTES + (sub % 3) * Cfg::B_BYTES + b_frag;
+#pragma unroll
+      for (int kk = 0; kk < 3; ++kk) {
+        if (lab & 2) continue;
+        bf16x8 af[TM], bfr[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * 48 + kk * 16);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(sb + j * 16 * 48 + kk * 16);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);  // C^T tile
+      }
+    };
+    // A wave is held at the issue of an LDS-DMA request while the load path is full (the fill runs at the L2's ~11 TB/s), and
+    // its MFMAs queue behind that in program order: with all eight waves in the same order the two halves of a sub-step simply
+    // add up (measured: 1.5 ms of requests + 1.5 ms of MFMAs + 0.9 ms skeleton = 4.0 ms).  The two waves of a SIMD (w, w + 4)
+    // therefore run the halves in opposite order: one requests while the other multiplies.
+    if (late) {
+      multiply();
+      __builtin_amdgcn_sched_barrier(0);
+      request();
+    } else {
+      request();
+      __builtin_amdgcn_sched_barrier(0);
+      multiply();
+    }
+    allow = (dw == kw - 1) ? issued - a_issued : issued;         // next sub-step starts a step: its segment must be complete
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // nothing is in flight here (sub + 2 < nsub guards); cheap
+
+  // rows of this tile are output pixels m0 + r; those past the end of the image row do not exist
+  if (lab & 4) return;
+  GemmParams pe = p;
+  const int64_t row_begin = ((int64_t)(bb * p.cv_T + to) * p.cv_H + ho) * p.cv_W;
+  pe.M = row_begin + p.cv_W;
+  gemm16_epilogue<TM, TN, EPI>(pe, acc, row_begin + w0 + wm * TM * 16, wn * TN * 16, r16, q);
+}
+
+template <int WM, int WN, int TM, int TN, int EPI>
+static int launch_conv_rows(GemmParams& p, hipStream_t s) {
+  using Cfg = ConvRowsCfg<WM, WN, TM, TN>;
+  const int tiles_per_row = (p.cv_W + Cfg::BM - 1) / Cfg::BM;
+  const int64_t n_tiles = (p.M / p.cv_W) * tiles_per_row;
+  LCV_CHECK_ARG(n_tiles < (int64_t(1) << 31), "conv3d: %ld row tiles", (long)n_tiles);
+  auto kern = conv_rows_kernel<WM, WN, TM, TN, EPI>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES) != hipSuccess) {
+      lcv_set_error("conv3d: cannot raise dynamic LDS to %d", Cfg::LDS_BYTES);
+      return LCV_EDEVICE;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)n_tiles), dim3(512), Cfg::LDS_BYTES, s, p, tiles_per_row, (int)n_tiles);
+  LCV_LAUNCH_CHECK("conv_rows");
+  return LCV_OK;
+}
+
+// Which convolutions take the row-tile kernel: stride 1, at most 3 taps along w, 96-channel slices, Cout <= 96, and rows long
+// enough that the last (partial) tile of a row does not dominate.
+static bool conv_rows_applies(const GemmParams& p, int64_t cin) {
+  if (getenv("LCV_CONV_ROWS") && atoi(getenv("LCV_CONV_ROWS")) == 0) return false;
+  if (p.cv_st != 1 || p.cv_sh != 1 || p.cv_sw != 1) return false;
+  if (cin % 96 != 0 || p.N > 96 || p.cv_kw > 3) return false;
+  const int tiles_per_row = (p.cv_W + 255) / 256;
+  return p.cv_W * 4 >= tiles_per_row * 256 * 3;     // >= 75 % of the tile rows are real pixels
+}

@@ -476,19 +476,43 @@ __global__ __launch_bounds__(WR* WC * 64) void gemm16_nt_kernel(const GemmParams
   const int ld_row = lane >> 3, ld_slot = lane & 7;
   int64_t a_row[Cfg::IA], b_row[Cfg::IB];
   int a_sw[Cfg::IA], b_sw[Cfg::IB];
-  int cv_t[Cfg::IA], cv_h[Cfg::IA], cv_w[Cfg::IA];  // conv mode: output pixel of each staged row
+  // conv mode, per staged row and once per output tile: the input pixel index of tap (0, 0, 0) - possibly outside the tensor -,
+  // one bit per tap saying whether that tap reads inside it (else: the zero page) and, for the folded 2x upsample, the parity
+  // of the upsampled row / column.  A K tile then costs one add, one bit test and one 64-bit multiply-add per row.  Deriving
+  // (t, h, w), the bounds and the pixel index anew for every K tile took ~130 vector instructions per 64 MFMAs, several of them
+  // quarter-rate integer multiplies: the convolution kernels were bound by address arithmetic, not by the matrix pipe.
+  int cv_pix0[Cfg::IA], a_sw2[Cfg::IA];
+  unsigned cv_ok[Cfg::IA], cv_par[Cfg::IA];
+  const bf16_t* b_ptr[Cfg::IB];   // conv mode: one K extent, so the weight row pointers are fixed
 #pragma unroll
   for (int t = 0; t < Cfg::IA; ++t) {
     const int row = (wave * Cfg::IA + t) * 8 + ld_row;
     int64_t g = m0 + row;
     a_row[t] = g > p.M - 1 ? p.M - 1 : g;
     a_sw[t] = (ld_slot ^ ((row >> 1) & 7)) * 8;
+    a_sw2[t] = a_sw[t] * 2;
     if constexpr (CONV) {
       int64_t r2 = a_row[t];
-      cv_w[t] = (int)(r2 % p.cv_W); r2 /= p.cv_W;
-      cv_h[t] = (int)(r2 % p.cv_H); r2 /= p.cv_H;
-      cv_t[t] = (int)(r2 % p.cv_T);
-      a_row[t] = r2 / p.cv_T;  // batch index
+      const int wo = (int)(r2 % p.cv_W); r2 /= p.cv_W;
+      const int ho = (int)(r2 % p.cv_H); r2 /= p.cv_H;
+      const int to = (int)(r2 % p.cv_T);
+      const int bb = (int)(r2 / p.cv_T);  // batch index
+      // front padding only: causal in t, (k/2 | 0) in h, w
+      const int t0 = to * p.cv_st - p.cv_pt, h0 = ho * p.cv_sh - p.cv_ph, w0 = wo * p.cv_sw - p.cv_pw;
+      const int hb = p.cv_up2x ? 2 * p.cv_Hin : p.cv_Hin, wb = p.cv_up2x ? 2 * p.cv_Win : p.cv_Win;
+      unsigned ok = 0;
+      int tap = 0;
+      for (int dt = 0; dt < p.cv_kt; ++dt)
+        for (int dh = 0; dh < p.cv_kh; ++dh)
+          for (int dw = 0; dw < p.cv_kw; ++dw, ++tap) {
+            const int ti = t0 + dt, hi = h0 + dh, wi = w0 + dw;
+            if (ti >= 0 && ti < p.cv_Tin && hi >= 0 && hi < hb && wi >= 0 && wi < wb) ok |= 1u << tap;
+          }
+      cv_ok[t] = ok;
+      // with the upsample: floor((x + d) / 2) = (x >> 1) + (((x & 1) + d) >> 1) for d >= 0 (arithmetic shift, x may be -1)
+      const int hq = p.cv_up2x ? (h0 >> 1) : h0, wq = p.cv_up2x ? (w0 >> 1) : w0;
+      cv_par[t] = p.cv_up2x ? (unsigned)((h0 & 1) | ((w0 & 1) << 1)) : 0u;
+      cv_pix0[t] = ((bb * p.cv_Tin + t0) * p.cv_Hin + hq) * p.cv_Win + wq;  // |.| < 2^31: the host checks the pixel count
     }
   }
 #pragma unroll
@@ -497,6 +521,7 @@ __global__ __launch_bounds__(WR* WC * 64) void gemm16_nt_kernel(const GemmParams
     int64_t g = n0 + row;
     b_row[t] = g > p.N - 1 ? p.N - 1 : g;
     b_sw[t] = (ld_slot ^ ((row >> 1) & 7)) * 8;
+    b_ptr[t] = p.w + b_row[t] * p.ldw + b_sw[t];
   }
   auto stage = [&](int kt, int buf) {
     const bf16_t* A = p.a;
@@ -512,16 +537,24 @@ __global__ __launch_bounds__(WR* WC * 64) void gemm16_nt_kernel(const GemmParams
       const int dw = tap % p.cv_kw;
       const int dh = (tap / p.cv_kw) % p.cv_kh;
       const int dt = tap / (p.cv_kw * p.cv_kh);
+      const int dpix_t = dt * p.cv_Hin * p.cv_Win;               // all scalar
+      const int dpix = dpix_t + dh * p.cv_Win + dw;
+      const unsigned row_bytes = (unsigned)p.lda * 2u;            // channels-last row of one pixel
+      const uint64_t abase = (uint64_t)(p.a + c0), zbase = (uint64_t)p.cv_zero;
 #pragma unroll
       for (int t = 0; t < Cfg::IA; ++t) {
-        const int ti = cv_t[t] * p.cv_st + dt - p.cv_pt;  // front padding only: causal in t, (k/2 | 0) in h, w
-        int hi = cv_h[t] * p.cv_sh + dh - p.cv_ph;
-        int wi = cv_w[t] * p.cv_sw + dw - p.cv_pw;
-        const int hb = p.cv_up2x ? 2 * p.cv_Hin : p.cv_Hin, wb = p.cv_up2x ? 2 * p.cv_Win : p.cv_Win;
-        const bool ok = ti >= 0 && ti < p.cv_Tin && hi >= 0 && hi < hb && wi >= 0 && wi < wb;
-        if (p.cv_up2x) { hi >>= 1; wi >>= 1; }
-        const int64_t pix = ((a_row[t] * p.cv_Tin + ti) * p.cv_Hin + hi) * (int64_t)p.cv_Win + wi;
-        const bf16_t* src = ok ? (A + pix * lda + c0 + a_sw[t]) : (p.cv_zero + a_sw[t]);
+        int pix;
+        if (p.cv_up2x) {
+          const int ih = (int)((cv_par[t] & 1u) + (unsigned)dh) >> 1, iw = (int)((cv_par[t] >> 1) + (unsigned)dw) >> 1;
+          pix = cv_pix0[t] + dpix_t + __mul24(ih, p.cv_Win) + iw;
+        } else {
+          pix = cv_pix0[t] + dpix;
+        }
+        // selects, not a branch: both sides are cheap and a divergent branch per row would serialise the four DMAs
+        const bool ok = (cv_ok[t] >> tap) & 1u;
+        const uint64_t base = ok ? abase : zbase;
+        const unsigned pm = ok ? (unsigned)pix : 0u;
+        const char* src = (const char*)(base + (uint64_t)pm * row_bytes + (unsigned)a_sw2[t]);
         __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(sa + (wave * Cfg::IA + t) * 1024), 16, 0, 0);
       }
     } else {
@@ -530,10 +563,16 @@ __global__ __launch_bounds__(WR* WC * 64) void gemm16_nt_kernel(const GemmParams
         __builtin_amdgcn_global_load_lds((gbl_void*)(A + a_row[t] * lda + k0 + a_sw[t]),
                                          (lds_void*)(sa + (wave * Cfg::IA + t) * 1024), 16, 0, 0);
     }
+    if constexpr (CONV) {
 #pragma unroll
-    for (int t = 0; t < Cfg::IB; ++t)
-      __builtin_amdgcn_global_load_lds((gbl_void*)(W + b_row[t] * ldw + k0 + b_sw[t]),
-                                       (lds_void*)(sb + (wave * Cfg::IB + t) * 1024), 16, 0, 0);
+      for (int t = 0; t < Cfg::IB; ++t)
+        __builtin_amdgcn_global_load_lds((gbl_void*)(b_ptr[t] + k0), (lds_void*)(sb + (wave * Cfg::IB + t) * 1024), 16, 0, 0);
+    } else {
+#pragma unroll
+      for (int t = 0; t < Cfg::IB; ++t)
+        __builtin_amdgcn_global_load_lds((gbl_void*)(W + b_row[t] * ldw + k0 + b_sw[t]),
+                                         (lds_void*)(sb + (wave * Cfg::IB + t) * 1024), 16, 0, 0);
+    }
   };
 
   f32x4v acc[TM][TN];
@@ -1127,10 +1166,16 @@ extern "C" int lcv_gemm_nt(const void* a, const void* w, const void* bias, const
   }
 }
 
+static thread_local const char* g_last_conv_kernel = "none";
+extern "C" const char* lcv_conv3d_last_kernel(void) { return g_last_conv_kernel; }
+
+#include "conv_rows.h"
+
 // ---------------------------------------------------------------------------
 // Causal 3-D convolution as an implicit GEMM on the same MFMA core (VAE decoder).
-//   x   [B, Tin, Hin, Win, Cin]  channels-last bf16, Cin % 64 == 0 (zero-padded channels)
-//   w   [Cout, kt*kh*kw*Cin]     K ordered (dt, dh, dw, cin)
+//   x   [B, Tin, Hin, Win, ldx]  channels-last bf16, Cin % 32 == 0 valid channels, ldx = roundup64(Cin), pad channels zero
+//   w   [Cout, kt*kh*kw*ldx]     K ordered (dt, dh, dw, cin)
+// Cin % 96 == 0 with Cout <= 96 at stride 1 takes the row-tile kernel (conv_rows.h), everything else the implicit GEMM.
 //   out [B, T, H, W, ldc] with T = Tin, (H, W) = (Hin, Win) or doubled when up2x (nearest upsample fused in the gather)
 // Temporal padding is causal (kt-1 zero frames in front), spatial padding kh/2, kw/2 zeros.
 // resid (nullable, same layout as out): out = resid + bf16(conv + bias)  (residual-block tail).
@@ -1139,20 +1184,33 @@ static int conv3d_impl(const void* x, const void* w, const void* bias, const voi
                        int64_t B, int64_t Tin, int64_t Hin, int64_t Win, int64_t Cin, int64_t Cout, int64_t ldc, int kt, int kh,
                        int kw, int up2x, int st, int sh, int sw, int pt, int ph, int pw, int64_t Tout, int64_t Hout,
                        int64_t Wout, void* stream) {
+  // the kernel keeps one validity bit per tap in a 32-bit word and 32-bit pixel indices per staged row
+  LCV_CHECK_ARG(kt * kh * kw <= 32, "conv3d: %d taps, at most 32 supported", kt * kh * kw);
+  LCV_CHECK_ARG(B * Tin * Hin * Win < (int64_t(1) << 31) && Cin <= 4096 && Cout <= 65536, "conv3d: input of %ld pixels is too large",
+                (long)(B * Tin * Hin * Win));
   GemmParams p{};
   p.a = (const bf16_t*)x; p.w = (const bf16_t*)w; p.bias = (const bf16_t*)bias; p.a2 = nullptr; p.w2 = nullptr;
   p.c = out;
   p.cv_T = (int)Tout; p.cv_H = (int)Hout; p.cv_W = (int)Wout;
   p.cv_Tin = (int)Tin; p.cv_Hin = (int)Hin; p.cv_Win = (int)Win;
-  p.cv_kt = kt; p.cv_kh = kh; p.cv_kw = kw; p.cv_cpt = (int)(Cin / 64); p.cv_up2x = up2x;
+  const int64_t ldx = (Cin + 63) / 64 * 64;   // pixel stride: channels are padded to a multiple of 64 (pads zero, also in w)
+  p.cv_kt = kt; p.cv_kh = kh; p.cv_kw = kw; p.cv_cpt = (int)(ldx / 64); p.cv_up2x = up2x;
   p.cv_st = st; p.cv_sh = sh; p.cv_sw = sw; p.cv_pt = pt; p.cv_ph = ph; p.cv_pw = pw;
   p.cv_zero = (const bf16_t*)zero_page;
   p.M = B * p.cv_T * (int64_t)p.cv_H * p.cv_W; p.N = Cout;
   p.nk1 = kt * kh * kw * p.cv_cpt; p.nk2 = 0;
-  p.lda = Cin; p.ldw = (int64_t)kt * kh * kw * Cin; p.lda2 = 0; p.ldw2 = 0; p.ldc = ldc; p.out_f32 = 0;
+  p.lda = ldx; p.ldw = (int64_t)kt * kh * kw * ldx; p.lda2 = 0; p.ldw2 = 0; p.ldc = ldc; p.out_f32 = 0;
   p.resid = (const bf16_t*)resid; p.gate = nullptr; p.rows_per_frame = 1; p.mod_stride = 0;
   if (p.M == 0) return LCV_OK;
   hipStream_t s = (hipStream_t)stream;
+  if (conv_rows_applies(p, Cin)) {
+    p.cv_cpt = (int)(Cin / 96);
+    p.splitk = getenv("LCV_CONV_LAB") ? atoi(getenv("LCV_CONV_LAB")) : 0;
+    g_last_conv_kernel = p.N <= 16 ? "conv_rows<256x16>" : "conv_rows<256x96>";
+    if (p.N <= 16) return resid ? launch_conv_rows<8, 1, 2, 1, LCV_EPI_GATE_RESIDUAL>(p, s) : launch_conv_rows<8, 1, 2, 1, LCV_EPI_NONE>(p, s);
+    return resid ? launch_conv_rows<4, 2, 4, 3, LCV_EPI_GATE_RESIDUAL>(p, s) : launch_conv_rows<4, 2, 4, 3, LCV_EPI_NONE>(p, s);
+  }
+  g_last_conv_kernel = p.N >= 192 ? "conv16_igemm<256x256>" : "conv16_igemm<128x128>";
   if (resid) return dispatch_conv<LCV_EPI_GATE_RESIDUAL>(p, s);
   return dispatch_conv<LCV_EPI_NONE>(p, s);
 }
@@ -1162,7 +1220,7 @@ extern "C" int lcv_causal_conv3d(const void* x, const void* w, const void* bias,
                                  int64_t Cin, int64_t Cout, int64_t ldc, int kt, int kh, int kw, int up2x,
                                  void* stream) {
   LCV_CHECK_ARG(x && w && out && zero_page, "causal_conv3d: null pointer");
-  LCV_CHECK_ARG(Cin > 0 && Cin % 64 == 0, "causal_conv3d: Cin=%ld must be a multiple of 64 (pad channels)", (long)Cin);
+  LCV_CHECK_ARG(Cin > 0 && Cin % 32 == 0, "causal_conv3d: Cin=%ld must be a multiple of 32", (long)Cin);
   LCV_CHECK_ARG(kt >= 1 && kh >= 1 && kw >= 1 && (kh & 1) && (kw & 1), "causal_conv3d: odd spatial kernels only");
   LCV_CHECK_ARG(ldc >= Cout, "causal_conv3d: ldc < Cout");
   return conv3d_impl(x, w, bias, resid, out, zero_page, B, Tin, Hin, Win, Cin, Cout, ldc, kt, kh, kw, up2x, 1, 1, 1, kt - 1,
@@ -1178,7 +1236,7 @@ extern "C" int lcv_conv3d_strided(const void* x, const void* w, const void* bias
                                   int64_t ldc, int kt, int kh, int kw, int st, int sh, int sw, int64_t Tout,
                                   int64_t Hout, int64_t Wout, void* stream) {
   LCV_CHECK_ARG(x && w && out && zero_page, "conv3d_strided: null pointer");
-  LCV_CHECK_ARG(Cin > 0 && Cin % 64 == 0, "conv3d_strided: Cin=%ld must be a multiple of 64 (pad channels)", (long)Cin);
+  LCV_CHECK_ARG(Cin > 0 && Cin % 32 == 0, "conv3d_strided: Cin=%ld must be a multiple of 32", (long)Cin);
   LCV_CHECK_ARG(kt >= 1 && kh >= 1 && kw >= 1 && st >= 1 && sh >= 1 && sw >= 1, "conv3d_strided: bad kernel / stride");
   LCV_CHECK_ARG(ldc >= Cout, "conv3d_strided: ldc < Cout");
   LCV_CHECK_ARG(Tout >= 0 && Hout >= 0 && Wout >= 0 && (Tout - 1) * st < Tin && (Hout - 1) * sh < Hin && (Wout - 1) * sw < Win,

@@ -103,6 +103,8 @@ def load():
     lib.lcv_last_error.argtypes = []
     lib.lcv_attn_fwd_last_kernel.restype = c_char_p
     lib.lcv_attn_fwd_last_kernel.argtypes = []
+    lib.lcv_conv3d_last_kernel.restype = c_char_p
+    lib.lcv_conv3d_last_kernel.argtypes = []
     lib.lcv_tn_skinny_ws_bytes.restype = c_int64     # a size, not a status
     lib.lcv_tn_skinny_ws_bytes.argtypes = [I64, I64, I64]
     for name, args in _SIGNATURES.items():

@@ -260,9 +260,11 @@ class AutoencoderKLWan(nn.Module):
         ldc = _pad64(conv.cout) if pad_out else conv.cout
         alloc = torch.zeros if ldc != conv.cout else torch.empty
         out = alloc((B, T, Ho, Wo, ldc), dtype=BF16, device=x.device)
+        # the real channel count when the library can use it (96-channel stages: row-tile kernel), else the padded pitch
+        cin = conv.cin if (conv.cin % 32 == 0 and _pad64(conv.cin) == Cp) else Cp
         call("lcv_causal_conv3d", x.data_ptr(), conv.packed().data_ptr(), conv.bias.data_ptr(),
              None if resid is None else resid.data_ptr(), out.data_ptr(), self._zero_page(x.device).data_ptr(),
-             B, T, H, W, Cp, conv.cout, ldc, k[0], k[1], k[2], 1 if up2x else 0, ops._stream())
+             B, T, H, W, cin, conv.cout, ldc, k[0], k[1], k[2], 1 if up2x else 0, ops._stream())
         return out
 
     def _norm(self, x, norm: _Norm, silu=True):

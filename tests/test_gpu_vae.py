@@ -50,6 +50,62 @@ def test_conv_kernel_against_conv3d():
         assert rel_l2(got, ref) < 3e-3, (ci, co, k, up)
 
 
+@pytest.mark.parametrize("ci,co,k,up,W,resid", [
+    (96, 96, (3, 3, 3), False, 200, False),     # one partial 256-pixel tile per image row
+    (96, 96, (3, 3, 3), False, 400, True),      # two tiles, the second partial; residual tail
+    (96, 3, (3, 3, 3), False, 256, False),      # the 3-channel head (16-column tile), exact tile
+    (192, 96, (3, 3), True, 200, False),        # folded 2x upsample: output rows of 400 pixels, two channel slices per tap
+    (192, 96, (1, 1, 1), False, 210, False),    # pointwise shortcut
+])
+def test_row_tile_conv_kernel(ci, co, k, up, W, resid, monkeypatch):
+    """conv_rows.h (96-channel stages) against torch's convolution, and against the implicit-GEMM kernel it replaces there
+    (LCV_CONV_ROWS=0): same products, another summation order."""
+    import torch.nn.functional as F
+    from longcat_video.modules.vae_wan import AutoencoderKLWan, _Conv
+    vae = AutoencoderKLWan(base_dim=16, z_dim=4, device="cuda", dtype=BF16)
+    g = torch.Generator().manual_seed(11)
+    T, H = 3, 5
+    conv = _Conv(ci, co, k, device="cuda", dtype=BF16)
+    taps = 1
+    for v in k:
+        taps *= v
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn((co, ci) + k, generator=g) * (ci * taps) ** -0.5)
+        conv.bias.copy_(torch.randn(co, generator=g) * 0.1)
+    cp = (ci + 63) // 64 * 64
+    x = torch.zeros(1, T, H, W, cp, dtype=BF16)
+    x[..., :ci] = torch.randn(1, T, H, W, ci, generator=g).to(BF16)
+    Ho, Wo = (2 * H, 2 * W) if up else (H, W)
+    r = None
+    if resid:
+        r = torch.zeros(1, T, Ho, Wo, (co + 63) // 64 * 64, dtype=BF16)
+        r[..., :co] = torch.randn(1, T, Ho, Wo, co, generator=g).to(BF16)
+    run = lambda: vae._conv(x.cuda(), conv, resid=None if r is None else r.cuda(), up2x=up, pad_out=(co != 3))
+    from lcv_hip import lib as _lib
+    got_full = run()
+    assert _lib.load().lcv_conv3d_last_kernel().decode().startswith("conv_rows")
+    got = got_full[..., :co].float().cpu()
+    assert float(got_full[..., co:].abs().max() if got_full.shape[-1] > co else 0) == 0       # padding channels stay zero
+    monkeypatch.setenv("LCV_CONV_ROWS", "0")
+    old = run()[..., :co].float().cpu()
+    assert _lib.load().lcv_conv3d_last_kernel().decode().startswith("conv16_igemm")
+    monkeypatch.delenv("LCV_CONV_ROWS")
+    xn = x[..., :ci].float().permute(0, 4, 1, 2, 3)
+    wf, bf = conv.weight.float().cpu(), conv.bias.float().cpu()
+    if len(k) == 2:
+        y = xn.permute(0, 2, 1, 3, 4).reshape(T, ci, H, W)
+        if up:
+            y = F.interpolate(y, scale_factor=(2.0, 2.0), mode="nearest-exact")
+        ref = F.conv2d(y, wf, bf, padding=1).view(1, T, co, Ho, Wo).permute(0, 1, 3, 4, 2)
+    else:
+        y = F.pad(xn, (k[2] // 2, k[2] // 2, k[1] // 2, k[1] // 2, k[0] - 1, 0))
+        ref = F.conv3d(y, wf, bf).permute(0, 2, 3, 4, 1)
+    if resid:
+        ref = r[..., :co].float() + ref.to(BF16).float()
+    assert rel_l2(got, ref) < 3e-3
+    assert rel_l2(got, old) < 3e-3 and not torch.equal(got, torch.zeros_like(got))
+
+
 @pytest.mark.parametrize("T", [1, 3])
 def test_vae_decode_matches_oracle(T):
     from oracle import vae_oracle as V
