@@ -18,13 +18,16 @@
 // LDS image.  The fragment of lane (r16, q) for K block kk is 16 bytes; a tap reads the same image at a row offset dw, so the
 // image must be conflict-free for ds_read_b128 under ANY row shift.  An XOR swizzle is not (it is tied to row mod 16), and a
 // padded row stride cannot be (the four 16-lane groups of ds_read_b128 mix rows {0-3, 12-15} of q with rows {4-11} of q + 1).
-// What is: one plane per q, rows 48 bytes apart, plane size a multiple of 256 bytes -
-//     addr(row, q, kk) = q * PLANE + row * 48 + kk * 16
-// The bank unit (addr / 16) mod 16 = (3 row + kk) mod 16 takes 16 different values over the 16 rows of a lane group whatever
-// the shift, because 3 is odd and the plane offset drops out.  The 48 bytes of a plane row are channels [24 q, 24 q + 24): the
-// MFMA K index is permuted (k = 8 (l >> 4) + e of block kk  <->  channel 24 q + 8 kk + e) identically for both operands, which
-// changes only the order of the fp32 sums.  LDS-DMA fills the planes linearly: lane l of piece g writes unit 64 g + l, i.e. row
-// (64 g + l) / 3, block (64 g + l) % 3, and fetches those 16 bytes from global memory.
+// What is: lanes q and q + 1 (never q and q + 2) meet in a lane group, so one plane per PARITY of q, rows 96 bytes apart, the
+// second plane 16 (mod 32) bytes behind a multiple of 256 -
+//     addr(row, q, kk) = (q & 1) * PLANE + row * 96 + (q >> 1) * 48 + kk * 16
+// Bank unit (addr / 16) mod 16 = (6 row + 3 (q >> 1) + kk + (q & 1)) mod 16: 6 row takes the 8 even values over the 8 rows a
+// lane group reads from one plane (rows {0-3, 12-15} or {4-11}, shifted by anything), and the other plane's 8 rows land on
+// the odd ones.  The 96 bytes of a plane row are channels [48 (q & 1), +48): the MFMA K index is permuted (k = 8 (l >> 4) + e
+// of block kk  <->  channel 48 (q & 1) + 24 (q >> 1) + 8 kk + e) identically for both operands, which changes only the order
+// of the fp32 sums.  LDS-DMA fills a plane linearly: lane l of piece c writes unit 64 c + l = 16-byte block (64 c + l) % 6 of
+// row (64 c + l) / 6, so one request covers ~11 pixel rows with 96 contiguous bytes each (a first version with four planes of
+// 48-byte rows touched 22-43 cache lines per request).
 #pragma once
 
 template <int WM, int WN, int TM, int TN>
@@ -32,18 +35,18 @@ struct ConvRowsCfg {
   static constexpr int BM = WM * TM * 16;           // 256 output pixels
   static constexpr int BN = WN * TN * 16;           // 96 (or 16: the 3-channel head)
   static constexpr int NW = WM * WN;                // 8 waves
-  static constexpr int A_PIECES_PER_PLANE = 13;     // 13 KiB >= (256 + 2) rows x 48 B, and 13312 % 256 == 0
-  static constexpr int PLA = A_PIECES_PER_PLANE * 1024;
-  static constexpr int A_BYTES = 4 * PLA;           // 53248
-  static constexpr int A_PIECES = 4 * A_PIECES_PER_PLANE;
-  static constexpr int PLB = BN * 48;               // 4608 / 768: both multiples of 256
-  static constexpr int B_BYTES = 4 * PLB;
-  static constexpr int B_PIECES = B_BYTES / 1024;   // 18 / 3
-  static constexpr int IA = (A_PIECES + NW - 1) / NW;   // 7 piece slots per wave (the last one half used)
+  static constexpr int A_PIECES_PER_PLANE = 25;     // 25 KiB >= (256 + 2) rows x 96 B
+  static constexpr int PLA = A_PIECES_PER_PLANE * 1024 + 16;   // plane offset = 16 (mod 32) bytes: see the bank argument
+  static constexpr int A_BYTES = 2 * PLA;           // 51232
+  static constexpr int A_PIECES = 2 * A_PIECES_PER_PLANE;
+  static constexpr int B_PIECES_PER_PLANE = (BN * 96 + 1023) / 1024;   // 9 / 2
+  static constexpr int PLB = B_PIECES_PER_PLANE * 1024 + 16;
+  static constexpr int B_BYTES = 2 * PLB;
+  static constexpr int B_PIECES = 2 * B_PIECES_PER_PLANE;   // 18 / 4
+  static constexpr int IA = (A_PIECES + NW - 1) / NW;   // 7 piece slots per wave
   static constexpr int IB = (B_PIECES + NW - 1) / NW;   // 3 / 1
-  static constexpr int LDS_BYTES = 2 * A_BYTES + 3 * B_BYTES;   // 161792 of 163840
+  static constexpr int LDS_BYTES = 2 * A_BYTES + 3 * B_BYTES;   // 157856 of 163840
   static_assert(BM == 256 && NW == 8, "conv_rows: 256-pixel tiles, 8 waves");
-  static_assert(PLB % 256 == 0 && B_BYTES % 1024 == 0, "conv_rows: weight planes must keep the bank phase");
 };
 
 template <int WM, int WN, int TM, int TN, int EPI>
@@ -85,7 +88,7 @@ __global__ __launch_bounds__(512) void conv_rows_kernel(const GemmParams p, cons
   const int nsub = nsteps * kw;
 
   // ---- staging plans (per lane, once per tile) ----
-  // pixel segment: piece slot t of this wave is piece g = 8 t + wave; unit (g % 13) * 64 + lane of plane g / 13
+  // pixel segment: piece slot t of this wave is piece g = 8 t + wave; unit (g % 25) * 64 + lane of plane g / 25
   unsigned a_off[Cfg::IA];
   const int wbound = p.cv_Win << up;
 #pragma unroll
@@ -93,23 +96,22 @@ __global__ __launch_bounds__(512) void conv_rows_kernel(const GemmParams p, cons
     const int g = t * Cfg::NW + wave;
     const int plane = g / Cfg::A_PIECES_PER_PLANE;
     const int u = (g - plane * Cfg::A_PIECES_PER_PLANE) * 64 + lane;
-    const int row = u / 3, kk = u - row * 3;
+    const int row = u / 6, blk = u - row * 6;
     const int uu = w0 - p.cv_pw + row;                           // (upsampled) input column of staged row `row`
     const bool ok = g < Cfg::A_PIECES && row < Cfg::BM + kw - 1 && uu >= 0 && uu < wbound;
-    a_off[t] = ok ? (unsigned)(((uu >> up) * ldx + plane * 24 + kk * 8) * 2) : 0xFFFFFFFFu;
+    a_off[t] = ok ? (unsigned)(((uu >> up) * ldx + plane * 48 + blk * 8) * 2) : 0xFFFFFFFFu;
   }
-  // weights of one tap: piece g = 8 t + wave; unit 64 g + lane -> plane, output channel n, block kk
+  // weights of one tap: piece g = 8 t + wave, the same unit order over Cout rows
   unsigned b_off[Cfg::IB];
 #pragma unroll
   for (int t = 0; t < Cfg::IB; ++t) {
     const int g = t * Cfg::NW + wave;
-    const int u = g * 64 + lane;
-    const int plane = u / (Cfg::BN * 3);
-    const int rem = u - plane * (Cfg::BN * 3);
-    int n = rem / 3;
-    const int kk = rem - n * 3;
+    const int plane = g / Cfg::B_PIECES_PER_PLANE;
+    const int u = (g - plane * Cfg::B_PIECES_PER_PLANE) * 64 + lane;
+    int n = u / 6;
+    const int blk = u - n * 6;
     if (n > (int)p.N - 1) n = (int)p.N - 1;                      // rows past Cout: any finite data, masked by the epilogue
-    b_off[t] = (unsigned)((n * (int)p.ldw + plane * 24 + kk * 8) * 2);
+    b_off[t] = (unsigned)((n * (int)p.ldw + plane * 48 + blk * 8) * 2);
   }
   const uint64_t zpage = (uint64_t)p.cv_zero + (unsigned)(lane & 7) * 16u;
 
@@ -133,7 +135,8 @@ __global__ __launch_bounds__(512) void conv_rows_kernel(const GemmParams p, cons
       if (g >= Cfg::A_PIECES) continue;                          // wave-uniform
       const bool ok = a_off[t] != 0xFFFFFFFFu;
       const uint64_t src = ok ? base + a_off[t] : zpage;
-      __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(dst + g * 1024), 16, 0, 0);
+      const int plane = g / Cfg::A_PIECES_PER_PLANE;
+      __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(dst + plane * Cfg::PLA + (g - plane * Cfg::A_PIECES_PER_PLANE) * 1024), 16, 0, 0);
     }
   };
   auto stage_weights = [&](int sub) {
@@ -147,7 +150,8 @@ __global__ __launch_bounds__(512) void conv_rows_kernel(const GemmParams p, cons
     for (int t = 0; t < Cfg::IB; ++t) {
       const int g = t * Cfg::NW + wave;
       if (g >= Cfg::B_PIECES) continue;                          // wave-uniform
-      __builtin_amdgcn_global_load_lds((gbl_void*)(base + b_off[t]), (lds_void*)(dst + g * 1024), 16, 0, 0);
+      const int plane = g / Cfg::B_PIECES_PER_PLANE;
+      __builtin_amdgcn_global_load_lds((gbl_void*)(base + b_off[t]), (lds_void*)(dst + plane * Cfg::PLB + (g - plane * Cfg::B_PIECES_PER_PLANE) * 1024), 16, 0, 0);
     }
   };
 
@@ -157,8 +161,8 @@ __global__ __launch_bounds__(512) void conv_rows_kernel(const GemmParams p, cons
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
-  const int a_frag = q * Cfg::PLA + (wm * TM * 16 + r16) * 48;
-  const int b_frag = q * Cfg::PLB + (wn * TN * 16 + r16) * 48;
+  const int a_frag = (q & 1) * Cfg::PLA + (wm * TM * 16 + r16) * 96 + (q >> 1) * 48;
+  const int b_frag = (q & 1) * Cfg::PLB + (wn * TN * 16 + r16) * 96 + (q >> 1) * 48;
 
   // ---- pipeline: loads run TWO sub-steps ahead of the MFMAs ----
   // One workgroup owns the CU (143-162 KB of LDS), so nothing else hides a DMA round trip: with the next sub-step's images
@@ -176,7 +180,7 @@ __global__ __launch_bounds__(512) void conv_rows_kernel(const GemmParams p, cons
     for (int t = 0; t < Cfg::IA; ++t) n += (t >= t_begin && t < t_end && t * Cfg::NW + wave < Cfg::A_PIECES) ? 1 : 0;
     return n;
   };
-  auto part_begin = [&](int dw) { return kw >= 3 ? (dw == 0 ? 0 : dw == 1 ? 4 : Cfg::IA) : (dw == 0 ? 0 : Cfg::IA); };
+  auto part_begin = [&](int dw) { return kw >= 3 ? (dw == 0 ? 0 : dw == 1 ? 4 : Cfg::IA) : (dw == 0 ? 0 : Cfg::IA); };   // IA = 7
   auto part_end = [&](int dw) { return kw >= 3 ? (dw == 0 ? 4 : Cfg::IA) : Cfg::IA; };
   auto wait_allow = [&](int n) {       // s_waitcnt takes an immediate
     switch (n) {
@@ -214,16 +218,16 @@ __global__ __launch_bounds__(512) void conv_rows_kernel(const GemmParams p, cons
       if (sub + 2 < nsub) { stage_weights(sub + 2); issued += nb_wave; }
     };
     auto multiply = [&]() {
-      const unsigned char* sa = smem + (step & 1) * Cfg::A_BYTES + a_frag + dw * 48;
+      const unsigned char* sa = smem + (step & 1) * Cfg::A_BYTES + a_frag + dw * 96;
       const unsigned char* sb = smem + 2 * Cfg::A_BYTES + (sub % 3) * Cfg::B_BYTES + b_frag;
 #pragma unroll
       for (int kk = 0; kk < 3; ++kk) {
         if (lab & 2) continue;
         bf16x8 af[TM], bfr[TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * 48 + kk * 16);
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * 96 + kk * 16);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(sb + j * 16 * 48 + kk * 16);
+        for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(sb + j * 16 * 96 + kk * 16);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
