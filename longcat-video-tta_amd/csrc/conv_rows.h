@@ -45,10 +45,32 @@ struct ConvRowsCfg {
   static constexpr int B_PIECES = 2 * B_PIECES_PER_PLANE;   // 18 / 4
   static constexpr int IA = (A_PIECES + NW - 1) / NW;   // 7 piece slots per wave
   static constexpr int IB = (B_PIECES + NW - 1) / NW;   // 3 / 1
-  static constexpr int LDS_BYTES = 2 * A_BYTES + 3 * B_BYTES;   // 157856 of 163840
+  static constexpr int IMAGE_BYTES = 2 * A_BYTES + 3 * B_BYTES;   // 157856
+  static constexpr int MAX_STEPS = 32, MAX_SUB = 64;             // table sizes (host-checked against kt * kh * slices, x kw)
+  static constexpr int TABLE = (IMAGE_BYTES + 15) / 16 * 16;
+  static constexpr int TABLE_BYTES = (MAX_STEPS + MAX_SUB) * 8;   // per tile parity
+  static constexpr int LDS_BYTES = TABLE + 2 * TABLE_BYTES;       // 159392 of 163840
   static_assert(BM == 256 && NW == 8, "conv_rows: 256-pixel tiles, 8 waves");
 };
 
+struct ConvRowsTile {          // what the sub-step loop and the epilogue need of one output tile (wave-uniform)
+  int nsteps, nsub;            // steps = valid (dt, dh) x channel slices; sub-steps = steps x kw
+  int w0;                      // first output column
+  int64_t row_begin;           // output row index m of column 0 of this image row
+};
+
+// Persistent: gridDim.x = 8 G workgroups, one per CU.  Workgroup (xcd = id % 8, slot = id / 8) walks tiles slot, slot + G, ...
+// of its XCD's contiguous run of the tile sequence, so the G workgroups of an XCD always work on G neighbouring tiles (a band
+// of image rows whose dh / dt neighbours stay in that XCD's L2) and the sub-step stream never stops: the first segment and
+// the first two taps' weights of the NEXT tile are requested during the last sub-steps of the current one and land while its
+// epilogue runs.
+//
+// The sub-step loop is kept free of index arithmetic.  A first version derived (dt, dh, slice, tap) and the two 64-bit source
+// bases from the sub-step number inside the loop: ~800 executed instructions per 36 MFMAs, most of them scalar divisions and
+// SGPR spill traffic (186 v_readlane per iteration) - phase stamps showed 2.0 us in a "request" of four LDS-DMA instructions and
+// request and MFMA times simply adding up.  Now one wave writes, once per tile, the source base of every step (pixel segment)
+// and sub-step (weights) into a small LDS table - one lane per sub-step, the divisions run 64 wide - and the loop advances
+// cursors over the tables of the current and the next tile.
 template <int WM, int WN, int TM, int TN, int EPI>
 __global__ __launch_bounds__(512) void conv_rows_kernel(const GemmParams p, const int tiles_per_row, const int n_tiles) {
   using Cfg = ConvRowsCfg<WM, WN, TM, TN>;
@@ -58,50 +80,81 @@ __global__ __launch_bounds__(512) void conv_rows_kernel(const GemmParams p, cons
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int r16 = lane & 15, q = lane >> 4;
-
-  // workgroup -> tile: ids that share an XCD (id % 8) walk one contiguous run of tiles, i.e. a band of image rows whose
-  // dh / dt neighbours stay in that XCD's L2
-  int pid;
-  {
-    const int orig = (int)blockIdx.x, xcd = orig & 7;
-    const int per = n_tiles >> 3, r8 = n_tiles & 7;
-    pid = (xcd < r8 ? xcd * (per + 1) : r8 * (per + 1) + (xcd - r8) * per) + (orig >> 3);
-  }
-  const int wt = pid % tiles_per_row;
-  int rowid = pid / tiles_per_row;
-  const int ho = rowid % p.cv_H; rowid /= p.cv_H;
-  const int to = rowid % p.cv_T;
-  const int bb = rowid / p.cv_T;
-  const int w0 = wt * Cfg::BM;
-  const int up = p.cv_up2x ? 1 : 0;
-  const int ldx = (int)p.lda;                                   // pixel stride of x in elements
-  const int ncs = p.cv_cpt;                                     // 96-channel slices per tap
-
-  // the (dt, dh) taps that read inside the tensor: ranges, since padding is in front (t) or symmetric (h) and stride is 1
-  const int t0 = to - p.cv_pt, h0 = ho - p.cv_ph;
-  const int hb = p.cv_Hin << up;
-  const int dt_lo = t0 < 0 ? -t0 : 0, dt_hi = (p.cv_Tin - t0) < p.cv_kt ? (p.cv_Tin - t0) : p.cv_kt;   // [lo, hi)
-  const int dh_lo = h0 < 0 ? -h0 : 0, dh_hi = (hb - h0) < p.cv_kh ? (hb - h0) : p.cv_kh;
-  const int ndh = dh_hi - dh_lo;
-  const int nsteps = (dt_hi - dt_lo) * ndh * ncs;
   const int kw = p.cv_kw;
-  const int nsub = nsteps * kw;
 
-  // ---- staging plans (per lane, once per tile) ----
-  // pixel segment: piece slot t of this wave is piece g = 8 t + wave; unit (g % 25) * 64 + lane of plane g / 25
-  unsigned a_off[Cfg::IA];
-  const int wbound = p.cv_Win << up;
-#pragma unroll
-  for (int t = 0; t < Cfg::IA; ++t) {
-    const int g = t * Cfg::NW + wave;
-    const int plane = g / Cfg::A_PIECES_PER_PLANE;
-    const int u = (g - plane * Cfg::A_PIECES_PER_PLANE) * 64 + lane;
-    const int row = u / 6, blk = u - row * 6;
-    const int uu = w0 - p.cv_pw + row;                           // (upsampled) input column of staged row `row`
-    const bool ok = g < Cfg::A_PIECES && row < Cfg::BM + kw - 1 && uu >= 0 && uu < wbound;
-    a_off[t] = ok ? (unsigned)(((uu >> up) * ldx + plane * 48 + blk * 8) * 2) : 0xFFFFFFFFu;
+  // this workgroup's tiles: first + k * stride while < last
+  int tile_next, tile_end;
+  const int tile_stride = (int)gridDim.x >> 3;
+  {
+    const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+    const int per = n_tiles >> 3, r8 = n_tiles & 7;
+    const int begin = xcd < r8 ? xcd * (per + 1) : r8 * (per + 1) + (xcd - r8) * per;
+    tile_end = begin + per + (xcd < r8 ? 1 : 0);
+    tile_next = begin + slot;
   }
-  // weights of one tap: piece g = 8 t + wave, the same unit order over Cout rows
+  if (tile_next >= tile_end) return;                             // (whole workgroup)
+
+  // ---- per-tile plan ----
+  // a_off: where each lane's LDS-DMA pieces of the pixel segment come from, relative to the start of the input image row
+  // (~0: outside, zero page).  Piece slot t of this wave is piece g = 8 t + wave; unit (g % 25) * 64 + lane of plane g / 25
+  // = 16-byte block u % 6 of staged row u / 6.
+  // Tables (LDS, per tile parity): tab_a[step] = address of channel slice cs of input image row (t0 + dt, (h0 + dh) >> up),
+  // tab_b[sub-step] = address of w[0][tap][96 cs]; steps enumerate the (dt, dh) taps that read inside the tensor (ranges, since
+  // padding is in front in t, symmetric in h, and the stride is 1) times the channel slices.
+  auto tab_a = [&](int parity, int i) { return reinterpret_cast<uint64_t*>(smem + Cfg::TABLE + parity * Cfg::TABLE_BYTES) + i; };
+  auto tab_b = [&](int parity, int i) { return tab_a(parity, Cfg::MAX_STEPS + i); };
+  auto plan_tile = [&](int pid, int parity, ConvRowsTile& c, unsigned (&a_off)[Cfg::IA]) {
+    const int up = p.cv_up2x ? 1 : 0;
+    const int ldx = (int)p.lda, ncs = p.cv_cpt;
+    const int wt = pid % tiles_per_row;
+    int rowid = pid / tiles_per_row;
+    const int ho = rowid % p.cv_H;
+    c.row_begin = (int64_t)rowid * p.cv_W;
+    rowid /= p.cv_H;
+    const int to = rowid % p.cv_T;
+    const int bb = rowid / p.cv_T;
+    c.w0 = wt * Cfg::BM;
+    const int t0 = to - p.cv_pt, h0 = ho - p.cv_ph;
+    const int hb = p.cv_Hin << up;
+    const int dt_lo = t0 < 0 ? -t0 : 0;
+    const int dt_hi = (p.cv_Tin - t0) < p.cv_kt ? (p.cv_Tin - t0) : p.cv_kt;
+    const int dh_lo = h0 < 0 ? -h0 : 0;
+    const int dh_hi = (hb - h0) < p.cv_kh ? (hb - h0) : p.cv_kh;
+    const int ndh = dh_hi - dh_lo;
+    c.nsteps = (dt_hi - dt_lo) * ndh * ncs;
+    c.nsub = c.nsteps * kw;
+    const int wbound = p.cv_Win << up;
+#pragma unroll
+    for (int t = 0; t < Cfg::IA; ++t) {
+      const int g = t * Cfg::NW + wave;
+      const int plane = g / Cfg::A_PIECES_PER_PLANE;
+      const int u = (g - plane * Cfg::A_PIECES_PER_PLANE) * 64 + lane;
+      const int row = u / 6, blk = u - row * 6;
+      const int uu = c.w0 - p.cv_pw + row;                       // (upsampled) input column of staged row `row`
+      const bool ok = g < Cfg::A_PIECES && row < Cfg::BM + kw - 1 && uu >= 0 && uu < wbound;
+      a_off[t] = ok ? (unsigned)(((uu >> up) * ldx + plane * 48 + blk * 8) * 2) : 0xFFFFFFFFu;
+    }
+    if (wave == 0) {                                             // lane l: sub-step l
+      if (lane < c.nsub) {
+        const int step = lane / kw, dw = lane - step * kw;
+        const int cs = step % ncs, r = step / ncs;
+        const int dh = dh_lo + r % ndh, dt = dt_lo + r / ndh;
+        const int tap = (dt * p.cv_kh + dh) * kw + dw;
+        *tab_b(parity, lane) = (uint64_t)(p.w + (int64_t)tap * ldx + cs * 96);
+        if (dw == 0) {
+          const int64_t in_row = ((int64_t)(bb * p.cv_Tin + t0 + dt) * p.cv_Hin + ((h0 + dh) >> up)) * p.cv_Win;
+          *tab_a(parity, step) = (uint64_t)(p.a + in_row * ldx + cs * 96);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // written before this wave's next barrier
+    }
+  };
+  auto table_entry = [&](const uint64_t* e) {                    // uniform LDS read -> scalar registers
+    const uint64_t v = *e;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+  };
+  // weights of one tap: piece g = 8 t + wave, the same unit order over Cout rows (tile-independent)
   unsigned b_off[Cfg::IB];
 #pragma unroll
   for (int t = 0; t < Cfg::IB; ++t) {
@@ -115,19 +168,9 @@ __global__ __launch_bounds__(512) void conv_rows_kernel(const GemmParams p, cons
   }
   const uint64_t zpage = (uint64_t)p.cv_zero + (unsigned)(lane & 7) * 16u;
 
-  // step -> (dt, dh, slice): scalar
-  auto step_coords = [&](int step, int& dt, int& dh, int& cs) {
-    cs = step % ncs;
-    const int r = step / ncs;
-    dh = dh_lo + r % ndh;
-    dt = dt_lo + r / ndh;
-  };
-  auto stage_pixels = [&](int step, int t_begin, int t_end) {
-    int dt, dh, cs;
-    step_coords(step, dt, dh, cs);
-    const int64_t in_row = ((int64_t)(bb * p.cv_Tin + t0 + dt) * p.cv_Hin + ((h0 + dh) >> up)) * p.cv_Win;
-    const uint64_t base = (uint64_t)(p.a + in_row * ldx + cs * 96);
-    unsigned char* dst = smem + (step & 1) * Cfg::A_BYTES;
+  // pieces [t_begin, t_end) of the segment at `base` into pixel buffer `buf`
+  auto stage_pixels = [&](uint64_t base, const unsigned (&a_off)[Cfg::IA], int buf, int t_begin, int t_end) {
+    unsigned char* dst = smem + buf * Cfg::A_BYTES;
 #pragma unroll
     for (int t = 0; t < Cfg::IA; ++t) {
       if (t < t_begin || t >= t_end) continue;
@@ -139,13 +182,8 @@ __global__ __launch_bounds__(512) void conv_rows_kernel(const GemmParams p, cons
       __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(dst + plane * Cfg::PLA + (g - plane * Cfg::A_PIECES_PER_PLANE) * 1024), 16, 0, 0);
     }
   };
-  auto stage_weights = [&](int sub) {
-    const int step = sub / kw, dw = sub - step * kw;
-    int dt, dh, cs;
-    step_coords(step, dt, dh, cs);
-    const int tap = (dt * p.cv_kh + dh) * kw + dw;
-    const uint64_t base = (uint64_t)(p.w + (int64_t)tap * ldx + cs * 96);
-    unsigned char* dst = smem + 2 * Cfg::A_BYTES + (sub % 3) * Cfg::B_BYTES;
+  auto stage_weights = [&](uint64_t base, int buf) {
+    unsigned char* dst = smem + 2 * Cfg::A_BYTES + buf * Cfg::B_BYTES;
 #pragma unroll
     for (int t = 0; t < Cfg::IB; ++t) {
       const int g = t * Cfg::NW + wave;
@@ -155,33 +193,17 @@ __global__ __launch_bounds__(512) void conv_rows_kernel(const GemmParams p, cons
     }
   };
 
-  f32x4v acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
-
-  const int a_frag = (q & 1) * Cfg::PLA + (wm * TM * 16 + r16) * 96 + (q >> 1) * 48;
-  const int b_frag = (q & 1) * Cfg::PLB + (wn * TN * 16 + r16) * 96 + (q >> 1) * 48;
-
   // ---- pipeline: loads run TWO sub-steps ahead of the MFMAs ----
-  // One workgroup owns the CU (143-162 KB of LDS), so nothing else hides a DMA round trip: with the next sub-step's images
-  // requested only one sub-step ahead, a sub-step took ~1.9 us against 0.5 us of MFMA work - the latency of a loaded L2, not
-  // its bandwidth (35 KB per sub-step and CU).  Weights of sub-step j + 2 and the next pixel segment (its pieces spread over
-  // the first two taps of the current step) are requested at sub-step j, into a third weight buffer; the wait at the top of a
-  // sub-step is counted: this wave's requests of the previous sub-step may stay in flight, except a segment part that
-  // completes the segment the coming sub-step starts on (those were issued before the weights, so they are the older ones).
+  // Weights of sub-step j + 2 and the next pixel segment (its pieces spread over the first two taps of the current step) are
+  // requested at sub-step j, into a third weight buffer; the wait at the top of a sub-step is counted: this wave's requests of
+  // the previous sub-step may stay in flight, except a segment part that completes the segment the coming sub-step starts on
+  // (those were issued before the weights, so they are the older ones).
   int nb_wave = 0;
 #pragma unroll
   for (int t = 0; t < Cfg::IB; ++t) nb_wave += (t * Cfg::NW + wave < Cfg::B_PIECES) ? 1 : 0;
-  auto na_wave = [&](int t_begin, int t_end) {
-    int n = 0;
-#pragma unroll
-    for (int t = 0; t < Cfg::IA; ++t) n += (t >= t_begin && t < t_end && t * Cfg::NW + wave < Cfg::A_PIECES) ? 1 : 0;
-    return n;
-  };
-  auto part_begin = [&](int dw) { return kw >= 3 ? (dw == 0 ? 0 : dw == 1 ? 4 : Cfg::IA) : (dw == 0 ? 0 : Cfg::IA); };   // IA = 7
-  auto part_end = [&](int dw) { return kw >= 3 ? (dw == 0 ? 4 : Cfg::IA) : Cfg::IA; };
+  // segment parts: pieces [0, 4) with the first tap, [4, 7) with the second (kw < 3: everything with the first)
+  const int na_part0 = kw >= 3 ? 4 : ((Cfg::IA - 1) * Cfg::NW + wave < Cfg::A_PIECES ? Cfg::IA : Cfg::IA - 1);
+  const int na_part1 = kw >= 3 ? ((Cfg::IA - 1) * Cfg::NW + wave < Cfg::A_PIECES ? Cfg::IA - 4 : Cfg::IA - 5) : 0;
   auto wait_allow = [&](int n) {       // s_waitcnt takes an immediate
     switch (n) {
       case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
@@ -195,69 +217,119 @@ __global__ __launch_bounds__(512) void conv_rows_kernel(const GemmParams p, cons
     }
   };
 
-  const int lab = p.splitk;   // scratch/pmc_conv.py only (LCV_CONV_LAB): 1 = no staging inside the loop, 2 = no MFMAs, 4 = no epilogue, 8 = all waves request first
-  const bool late = wave >= 4 && !(lab & 8);
-  int allow = 0;
-  if (nsub > 0) {
-    stage_pixels(0, 0, Cfg::IA);
-    stage_weights(0);
-    if (nsub > 1) { stage_weights(1); allow = nb_wave; }
-  }
-  for (int sub = 0; sub < nsub; ++sub) {
-    const int step = sub / kw, dw = sub - step * kw;
-    wait_allow(allow);                                           // this sub-step's images have landed (this wave's part)
-    __builtin_amdgcn_s_barrier();                                // ... everyone's; and all waves are done with sub-step sub - 1
-    int issued = 0, a_issued = 0;
-    auto request = [&]() {
-      if (lab & 1) return;
-      if (step + 1 < nsteps) {                                   // segment of the next step (older than the weights below)
-        stage_pixels(step + 1, part_begin(dw), part_end(dw));
-        a_issued = na_wave(part_begin(dw), part_end(dw));
-        issued += a_issued;
-      }
-      if (sub + 2 < nsub) { stage_weights(sub + 2); issued += nb_wave; }
-    };
-    auto multiply = [&]() {
-      const unsigned char* sa = smem + (step & 1) * Cfg::A_BYTES + a_frag + dw * 96;
-      const unsigned char* sb = smem + 2 * Cfg::A_BYTES + (sub % 3) * Cfg::B_BYTES + b_frag;
+  f32x4v acc[TM][TN];
 #pragma unroll
-      for (int kk = 0; kk < 3; ++kk) {
-        if (lab & 2) continue;
-        bf16x8 af[TM], bfr[TN];
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * 96 + kk * 16);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(sb + j * 16 * 96 + kk * 16);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);  // C^T tile
-      }
-    };
-    // A wave is held at the issue of an LDS-DMA request while the load path is full (the fill runs at the L2's ~11 TB/s), and
-    // its MFMAs queue behind that in program order: with all eight waves in the same order the two halves of a sub-step simply
-    // add up (measured: 1.5 ms of requests + 1.5 ms of MFMAs + 0.9 ms skeleton = 4.0 ms).  The two waves of a SIMD (w, w + 4)
-    // therefore run the halves in opposite order: one requests while the other multiplies.
-    if (late) {
-      multiply();
-      __builtin_amdgcn_sched_barrier(0);
-      request();
-    } else {
-      request();
-      __builtin_amdgcn_sched_barrier(0);
-      multiply();
-    }
-    allow = (dw == kw - 1) ? issued - a_issued : issued;         // next sub-step starts a step: its segment must be complete
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // nothing is in flight here (sub + 2 < nsub guards); cheap
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  const int a_frag = (q & 1) * Cfg::PLA + (wm * TM * 16 + r16) * 96 + (q >> 1) * 48;
+  const int b_frag = 2 * Cfg::A_BYTES + (q & 1) * Cfg::PLB + (wn * TN * 16 + r16) * 96 + (q >> 1) * 48;
+  // A wave is held at the issue of an LDS-DMA request while the load path is full, and its MFMAs queue behind that in program
+  // order; the two waves of a SIMD (w, w + 4) therefore run the two halves of a sub-step in opposite order.
+  const bool late = wave >= 4;
 
-  // rows of this tile are output pixels m0 + r; those past the end of the image row do not exist
-  if (lab & 4) return;
-  GemmParams pe = p;
-  const int64_t row_begin = ((int64_t)(bb * p.cv_T + to) * p.cv_H + ho) * p.cv_W;
-  pe.M = row_begin + p.cv_W;
-  gemm16_epilogue<TM, TN, EPI>(pe, acc, row_begin + w0 + wm * TM * 16, wn * TN * 16, r16, q);
+  ConvRowsTile cur, nxt;
+  unsigned a_cur[Cfg::IA], a_nxt[Cfg::IA];
+  int par = 0;                                                   // table parity of cur
+  plan_tile(tile_next, 0, cur, a_cur);
+  tile_next += tile_stride;
+  bool has_nxt = tile_next < tile_end;
+  if (has_nxt) plan_tile(tile_next, 1, nxt, a_nxt);
+  else nxt = cur;
+  __syncthreads();                                               // tables visible
+  stage_pixels(table_entry(tab_a(0, 0)), a_cur, 0, 0, Cfg::IA);
+  stage_weights(table_entry(tab_b(0, 0)), 0);
+  stage_weights(table_entry(tab_b(0, 1)), 1);                    // every tile has >= 2 sub-steps (host-checked)
+  int allow = nb_wave;
+  int abuf = 0, bbuf = 0;                                        // buffers of the step / sub-step being multiplied
+  // request cursors: weights of sub-step (current + 2), segment of step (current + 1); `_nx`: the cursor is in the next tile
+  int rb_idx = 2, rb_buf = 2, ra_idx = 1;
+  bool rb_nx = false, ra_nx = false;
+  auto normalize = [&]() {
+    if (!rb_nx && rb_idx >= cur.nsub) { rb_idx -= cur.nsub; rb_nx = true; }
+    if (!ra_nx && ra_idx >= cur.nsteps) { ra_idx -= cur.nsteps; ra_nx = true; }
+  };
+  normalize();
+
+  for (;;) {
+    int dw = 0;
+    for (int sub = 0; sub < cur.nsub; ++sub) {
+      wait_allow(allow);                                         // this sub-step's images have landed (this wave's part)
+      __builtin_amdgcn_s_barrier();                              // ... everyone's; and all waves are done with the sub-step before
+      int issued = 0, a_issued = 0;
+      auto request = [&]() {
+        if (dw < 2 && (!ra_nx || has_nxt)) {                     // segment of the next step (older than the weights below)
+          const uint64_t base = table_entry(tab_a(par ^ (ra_nx ? 1 : 0), ra_idx));
+          const int tb = dw == 0 ? 0 : (kw >= 3 ? 4 : Cfg::IA), te = dw == 0 ? (kw >= 3 ? 4 : Cfg::IA) : Cfg::IA;
+          if (ra_nx) stage_pixels(base, a_nxt, abuf ^ 1, tb, te);
+          else stage_pixels(base, a_cur, abuf ^ 1, tb, te);
+          a_issued = dw == 0 ? na_part0 : na_part1;
+          issued = a_issued;
+        }
+        if (!rb_nx || has_nxt) {
+          stage_weights(table_entry(tab_b(par ^ (rb_nx ? 1 : 0), rb_idx)), rb_buf);
+          issued += nb_wave;
+        }
+      };
+      auto multiply = [&]() {
+        const unsigned char* sa = smem + abuf * Cfg::A_BYTES + a_frag + dw * 96;
+        const unsigned char* sb = smem + bbuf * Cfg::B_BYTES + b_frag;
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) {
+          bf16x8 af[TM], bfr[TN];
+#pragma unroll
+          for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * 96 + kk * 16);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(sb + j * 16 * 96 + kk * 16);
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);  // C^T tile
+        }
+      };
+      if (late) {
+        multiply();
+        __builtin_amdgcn_sched_barrier(0);
+        request();
+      } else {
+        request();
+        __builtin_amdgcn_sched_barrier(0);
+        multiply();
+      }
+      // advance: buffers, cursors
+      bbuf = bbuf == 2 ? 0 : bbuf + 1;
+      rb_buf = rb_buf == 2 ? 0 : rb_buf + 1;
+      ++rb_idx;
+      const bool step_ends = dw == kw - 1;
+      allow = step_ends ? issued - a_issued : issued;            // next sub-step starts a step: its segment must be complete
+      if (step_ends) { dw = 0; abuf ^= 1; ++ra_idx; } else ++dw;
+      normalize();
+    }
+
+    // rows of this tile are output pixels row_begin + w0 + r; those past the end of the image row do not exist
+    {
+      GemmParams pe = p;
+      pe.M = cur.row_begin + p.cv_W;
+      gemm16_epilogue<TM, TN, EPI>(pe, acc, cur.row_begin + cur.w0 + wm * TM * 16, wn * TN * 16, r16, q);
+    }
+    if (!has_nxt) break;
+    cur = nxt;
+#pragma unroll
+    for (int t = 0; t < Cfg::IA; ++t) a_cur[t] = a_nxt[t];
+    par ^= 1;
+    rb_nx = false; ra_nx = false;                                // the cursors were in this tile already
+    tile_next += tile_stride;
+    has_nxt = tile_next < tile_end;
+    if (has_nxt) plan_tile(tile_next, par ^ 1, nxt, a_nxt);
+    normalize();
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    allow = 0;      // the next tile's first images AND this tile's stores (younger, so a counted wait could not skip them)
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 template <int WM, int WN, int TM, int TN, int EPI>
@@ -275,7 +347,11 @@ static int launch_conv_rows(GemmParams& p, hipStream_t s) {
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)n_tiles), dim3(512), Cfg::LDS_BYTES, s, p, tiles_per_row, (int)n_tiles);
+  // one workgroup per CU, a multiple of 8 (XCDs); fewer when there are fewer tiles
+  int grid = 256;
+  { const char* e = getenv("LCV_CONV_ROWS_GRID"); if (e && atoi(e) >= 8) grid = atoi(e) / 8 * 8; }
+  if ((int64_t)grid > (n_tiles + 7) / 8 * 8) grid = (int)((n_tiles + 7) / 8 * 8);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), Cfg::LDS_BYTES, s, p, tiles_per_row, (int)n_tiles);
   LCV_LAUNCH_CHECK("conv_rows");
   return LCV_OK;
 }
@@ -286,6 +362,9 @@ static bool conv_rows_applies(const GemmParams& p, int64_t cin) {
   if (getenv("LCV_CONV_ROWS") && atoi(getenv("LCV_CONV_ROWS")) == 0) return false;
   if (p.cv_st != 1 || p.cv_sh != 1 || p.cv_sw != 1) return false;
   if (cin % 96 != 0 || p.N > 96 || p.cv_kw > 3) return false;
+  const int slices = (int)(cin / 96);
+  if (slices * p.cv_kw * (p.cv_kh > 1 ? 2 : 1) < 2) return false;   // the pipeline wants >= 2 sub-steps in every tile
+  if (p.cv_kt * p.cv_kh * slices > 32 || p.cv_kt * p.cv_kh * slices * p.cv_kw > 64) return false;   // plan tables
   const int tiles_per_row = (p.cv_W + 255) / 256;
   return p.cv_W * 4 >= tiles_per_row * 256 * 3;     // >= 75 % of the tile rows are real pixels
 }

@@ -1205,7 +1205,6 @@ static int conv3d_impl(const void* x, const void* w, const void* bias, const voi
   hipStream_t s = (hipStream_t)stream;
   if (conv_rows_applies(p, Cin)) {
     p.cv_cpt = (int)(Cin / 96);
-    p.splitk = getenv("LCV_CONV_LAB") ? atoi(getenv("LCV_CONV_LAB")) : 0;
     g_last_conv_kernel = p.N <= 16 ? "conv_rows<256x16>" : "conv_rows<256x96>";
     if (p.N <= 16) return resid ? launch_conv_rows<8, 1, 2, 1, LCV_EPI_GATE_RESIDUAL>(p, s) : launch_conv_rows<8, 1, 2, 1, LCV_EPI_NONE>(p, s);
     return resid ? launch_conv_rows<4, 2, 4, 3, LCV_EPI_GATE_RESIDUAL>(p, s) : launch_conv_rows<4, 2, 4, 3, LCV_EPI_NONE>(p, s);
