@@ -96,7 +96,7 @@ __global__ __launch_bounds__(512) void conv_rows_kernel(const GemmParams p, cons
 
   // ---- per-tile plan ----
   // a_off: where each lane's LDS-DMA pieces of the pixel segment come from, relative to the start of the input image row
-  // (~0: outside, zero page).  Piece slot t of this wave is piece g = 8 t + wave; unit (g % 25) * 64 + lane of plane g / 25
+  // (2^31: outside - the buffer range check returns zeros).  Piece slot t of this wave is piece g = 8 t + wave; unit (g % 25) * 64 + lane of plane g / 25
   // = 16-byte block u % 6 of staged row u / 6.
   // Tables (LDS, per tile parity): tab_a[step] = address of channel slice cs of input image row (t0 + dt, (h0 + dh) >> up),
   // tab_b[sub-step] = address of w[0][tap][96 cs]; steps enumerate the (dt, dh) taps that read inside the tensor (ranges, since
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(512) void conv_rows_kernel(const GemmParams p, cons
       const int row = u / 6, blk = u - row * 6;
       const int uu = c.w0 - p.cv_pw + row;                       // (upsampled) input column of staged row `row`
       const bool ok = g < Cfg::A_PIECES && row < Cfg::BM + kw - 1 && uu >= 0 && uu < wbound;
-      a_off[t] = ok ? (unsigned)(((uu >> up) * ldx + plane * 48 + blk * 8) * 2) : 0xFFFFFFFFu;
+      a_off[t] = ok ? (unsigned)(((uu >> up) * ldx + plane * 48 + blk * 8) * 2) : 0x80000000u;   // outside: past any num_records
     }
     if (wave == 0) {                                             // lane l: sub-step l
       if (lane < c.nsub) {
@@ -166,30 +166,36 @@ __global__ __launch_bounds__(512) void conv_rows_kernel(const GemmParams p, cons
     if (n > (int)p.N - 1) n = (int)p.N - 1;                      // rows past Cout: any finite data, masked by the epilogue
     b_off[t] = (unsigned)((n * (int)p.ldw + plane * 48 + blk * 8) * 2);
   }
-  const uint64_t zpage = (uint64_t)p.cv_zero + (unsigned)(lane & 7) * 16u;
-
-  // pieces [t_begin, t_end) of the segment at `base` into pixel buffer `buf`
+  // Requests are buffer loads into LDS (buffer_load_dwordx4 ... offen lds): a 128-bit resource built from the scalar table
+  // entry, the lane's 32-bit offset from the plan, and the hardware range check as the zero padding - a lane whose offset is
+  // past num_records (the "outside" mark) gets zeros written to its LDS slot.  No vector instruction per piece; the global-load
+  // form needed a 64-bit add, a compare and two selects per piece against a zero page.
+  const int row_bytes = p.cv_Win * (int)p.lda * 2;               // one input image row
+  const int w_bytes = (int)(p.N * p.ldw * 2);
   auto stage_pixels = [&](uint64_t base, const unsigned (&a_off)[Cfg::IA], int buf, int t_begin, int t_end) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, row_bytes, 0x00020000);
     unsigned char* dst = smem + buf * Cfg::A_BYTES;
 #pragma unroll
     for (int t = 0; t < Cfg::IA; ++t) {
       if (t < t_begin || t >= t_end) continue;
       const int g = t * Cfg::NW + wave;
       if (g >= Cfg::A_PIECES) continue;                          // wave-uniform
-      const bool ok = a_off[t] != 0xFFFFFFFFu;
-      const uint64_t src = ok ? base + a_off[t] : zpage;
       const int plane = g / Cfg::A_PIECES_PER_PLANE;
-      __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(dst + plane * Cfg::PLA + (g - plane * Cfg::A_PIECES_PER_PLANE) * 1024), 16, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(dst + plane * Cfg::PLA + (g - plane * Cfg::A_PIECES_PER_PLANE) * 1024), 16,
+                                               (int)a_off[t], 0, 0, 0);
     }
   };
-  auto stage_weights = [&](uint64_t base, int buf) {
+  auto stage_weights = [&](uint64_t base, int buf, int t_begin = 0, int t_end = Cfg::IB) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, w_bytes, 0x00020000);
     unsigned char* dst = smem + 2 * Cfg::A_BYTES + buf * Cfg::B_BYTES;
 #pragma unroll
     for (int t = 0; t < Cfg::IB; ++t) {
+      if (t < t_begin || t >= t_end) continue;
       const int g = t * Cfg::NW + wave;
       if (g >= Cfg::B_PIECES) continue;                          // wave-uniform
       const int plane = g / Cfg::B_PIECES_PER_PLANE;
-      __builtin_amdgcn_global_load_lds((gbl_void*)(base + b_off[t]), (lds_void*)(dst + plane * Cfg::PLB + (g - plane * Cfg::B_PIECES_PER_PLANE) * 1024), 16, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(dst + plane * Cfg::PLB + (g - plane * Cfg::B_PIECES_PER_PLANE) * 1024), 16,
+                                               (int)b_off[t], 0, 0, 0);
     }
   };
 
@@ -224,10 +230,7 @@ __global__ __launch_bounds__(512) void conv_rows_kernel(const GemmParams p, cons
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
   const int a_frag = (q & 1) * Cfg::PLA + (wm * TM * 16 + r16) * 96 + (q >> 1) * 48;
   const int b_frag = 2 * Cfg::A_BYTES + (q & 1) * Cfg::PLB + (wn * TN * 16 + r16) * 96 + (q >> 1) * 48;
-  // A wave is held at the issue of an LDS-DMA request while the load path is full, and its MFMAs queue behind that in program
-  // order; the two waves of a SIMD (w, w + 4) therefore run the two halves of a sub-step in opposite order.
   const bool late = wave >= 4;
-
   ConvRowsTile cur, nxt;
   unsigned a_cur[Cfg::IA], a_nxt[Cfg::IA];
   int par = 0;                                                   // table parity of cur
@@ -256,6 +259,10 @@ __global__ __launch_bounds__(512) void conv_rows_kernel(const GemmParams p, cons
     for (int sub = 0; sub < cur.nsub; ++sub) {
       wait_allow(allow);                                         // this sub-step's images have landed (this wave's part)
       __builtin_amdgcn_s_barrier();                              // ... everyone's; and all waves are done with the sub-step before
+      // The two waves of a SIMD (w, w + 4) run the two halves of a sub-step - request, multiply - in opposite order: a wave is
+      // held 100-200 cycles at the issue of every LDS-DMA instruction, and its MFMAs queue behind that in program order.
+      // (Dealing the requests out between the K blocks' MFMAs of the same wave, with all 21 fragment reads up front, was slower:
+      // 3.5 vs 3.2 ms.)
       int issued = 0, a_issued = 0;
       auto request = [&]() {
         if (dw < 2 && (!ra_nx || has_nxt)) {                     // segment of the next step (older than the weights below)
@@ -306,7 +313,6 @@ __global__ __launch_bounds__(512) void conv_rows_kernel(const GemmParams p, cons
       if (step_ends) { dw = 0; abuf ^= 1; ++ra_idx; } else ++dw;
       normalize();
     }
-
     // rows of this tile are output pixels row_begin + w0 + r; those past the end of the image row do not exist
     {
       GemmParams pe = p;

@@ -1186,8 +1186,9 @@ static int conv3d_impl(const void* x, const void* w, const void* bias, const voi
                        int64_t Wout, void* stream) {
   // the kernel keeps one validity bit per tap in a 32-bit word and 32-bit pixel indices per staged row
   LCV_CHECK_ARG(kt * kh * kw <= 32, "conv3d: %d taps, at most 32 supported", kt * kh * kw);
-  LCV_CHECK_ARG(B * Tin * Hin * Win < (int64_t(1) << 31) && Cin <= 4096 && Cout <= 65536, "conv3d: input of %ld pixels is too large",
-                (long)(B * Tin * Hin * Win));
+  LCV_CHECK_ARG(B * Tin * Hin * Win < (int64_t(1) << 31) && Cin <= 4096 && Cout <= 65536 && Win * ((Cin + 63) / 64 * 64) * 2 < (int64_t(1) << 30) &&
+                    Cout * (int64_t)kt * kh * kw * ((Cin + 63) / 64 * 64) * 2 < (int64_t(1) << 31),
+                "conv3d: input of %ld pixels is too large", (long)(B * Tin * Hin * Win));
   GemmParams p{};
   p.a = (const bf16_t*)x; p.w = (const bf16_t*)w; p.bias = (const bf16_t*)bias; p.a2 = nullptr; p.w2 = nullptr;
   p.c = out;
