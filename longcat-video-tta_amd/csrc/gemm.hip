@@ -659,7 +659,11 @@ __device__ __forceinline__ void wait_vmcnt() {
 // so a workgroup keeps its XCD's run of the sequence), and the LDS-DMA prologue of the NEXT tile is issued before the
 // epilogue of the current one - the 128 KiB LDS image allows one workgroup per CU, so without this every tile exposes
 // its own pipeline fill and its store tail.
-template <int EPI, bool PERSIST, bool SPLIT = false>
+// CONV: the A operand is the implicit-GEMM gather of a causal convolution (conv3d_impl): K tile kts = (tap, 64-channel chunk),
+// row m = output pixel.  Per staged row and output tile the kernel keeps the pixel index of tap (0, 0, 0), one validity bit
+// per tap and the parity bits of the folded upsample; per K tile the tap's coordinates come from a small LDS table behind
+// the two K-tile buffers (filled once per workgroup, the divisions 256 wide) - no index arithmetic in the phase loop.
+template <int EPI, bool PERSIST, bool SPLIT = false, bool CONV = false>
 __global__ __launch_bounds__(512) void gemm8p_nt_kernel(const GemmParams p) {
   constexpr int BUF_BYTES = 65536, SLOT_BYTES = 16384;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -685,7 +689,11 @@ __global__ __launch_bounds__(512) void gemm8p_nt_kernel(const GemmParams p) {
   // (lane & 7) which holds logical chunk (lane & 7) ^ ((row >> 1) & 7).  Per-lane state is the (clamped) global row of
   // each of the 8 instructions; the source is  uniform base + K offset (SGPRs)  +  row * row-bytes + swizzle (32-bit VGPR) ----
   int arow[2][2], wrow[2][2];  // [mq | nq][t]
+  unsigned cv_ok[2][2], cv_par[2][2];   // CONV: arow = pixel index of tap (0, 0, 0); validity bit per tap; upsample parities
   unsigned swz[2];
+  // CONV: the K-tile cursor of each A stream (mq = 0, 1): both are staged for K tiles 0, 1, 2, ... of a tile in order, so the
+  // tap coordinates advance by scalar increments (reset by the prologue) instead of being derived from kts by divisions
+  int cvc_chunk[2] = {0, 0}, cvc_dw[2] = {0, 0}, cvc_dh[2] = {0, 0}, cvc_dt[2] = {0, 0}, cvc_tap[2] = {0, 0};
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int srow = 8 * (2 * wave + t) + (lane >> 3);
@@ -704,6 +712,27 @@ __global__ __launch_bounds__(512) void gemm8p_nt_kernel(const GemmParams p) {
       for (int h = 0; h < 2; ++h) {
         int64_t g = m0 + (srow >> 6) * 128 + h * 64 + (srow & 63);
         arow[h][t] = (int)(g > p.M - 1 ? p.M - 1 : g);
+        if constexpr (CONV) {
+          int64_t r2 = arow[h][t];
+          const int wo = (int)(r2 % p.cv_W); r2 /= p.cv_W;
+          const int ho = (int)(r2 % p.cv_H); r2 /= p.cv_H;
+          const int to = (int)(r2 % p.cv_T);
+          const int bb = (int)(r2 / p.cv_T);
+          const int t0 = to * p.cv_st - p.cv_pt, h0 = ho * p.cv_sh - p.cv_ph, w0 = wo * p.cv_sw - p.cv_pw;
+          const int hb = p.cv_up2x ? 2 * p.cv_Hin : p.cv_Hin, wb = p.cv_up2x ? 2 * p.cv_Win : p.cv_Win;
+          unsigned ok = 0;
+          int tap = 0;
+          for (int dt = 0; dt < p.cv_kt; ++dt)
+            for (int dh = 0; dh < p.cv_kh; ++dh)
+              for (int dw = 0; dw < p.cv_kw; ++dw, ++tap) {
+                const int ti = t0 + dt, hi = h0 + dh, wi = w0 + dw;
+                if (ti >= 0 && ti < p.cv_Tin && hi >= 0 && hi < hb && wi >= 0 && wi < wb) ok |= 1u << tap;
+              }
+          cv_ok[h][t] = ok;
+          const int hq = p.cv_up2x ? (h0 >> 1) : h0, wq = p.cv_up2x ? (w0 >> 1) : w0;
+          cv_par[h][t] = p.cv_up2x ? (unsigned)((h0 & 1) | ((w0 & 1) << 1)) : 0u;
+          arow[h][t] = ((bb * p.cv_Tin + t0) * p.cv_Hin + hq) * p.cv_Win + wq;
+        }
         g = n0 + (srow >> 5) * 64 + h * 32 + (srow & 31);
         wrow[h][t] = (int)(g > p.N - 1 ? p.N - 1 : g);
       }
@@ -718,6 +747,31 @@ __global__ __launch_bounds__(512) void gemm8p_nt_kernel(const GemmParams p) {
     const char* base = lora ? (const char*)p.a2 + (int64_t)(kts - p.nk1) * 128 : (const char*)p.a + (int64_t)kts * 128;
     const unsigned ldb = (unsigned)(lora ? p.lda2 : p.lda) * 2u;
     unsigned char* dst = smem + buf * BUF_BYTES + mq * SLOT_BYTES + wave * 2048;
+    if constexpr (CONV) {
+      const int tap = cvc_tap[mq], dh = cvc_dh[mq], dw = cvc_dw[mq], chunk = cvc_chunk[mq];
+      const int dpix_t = cvc_dt[mq] * p.cv_Hin * p.cv_Win;
+      if (++cvc_chunk[mq] == p.cv_cpt) {            // advance to the K tile this stream stages next
+        cvc_chunk[mq] = 0; ++cvc_tap[mq];
+        if (++cvc_dw[mq] == p.cv_kw) { cvc_dw[mq] = 0; if (++cvc_dh[mq] == p.cv_kh) { cvc_dh[mq] = 0; ++cvc_dt[mq]; } }
+      }
+      const uint64_t abase = (uint64_t)(p.a + chunk * 64), zbase = (uint64_t)p.cv_zero;
+      const unsigned row_b = (unsigned)p.lda * 2u;
+      const int dpix = dpix_t + dh * p.cv_Win + dw;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        int pix;
+        if (p.cv_up2x) {
+          const int ih = (int)((cv_par[mq][t] & 1u) + (unsigned)dh) >> 1, iw = (int)((cv_par[mq][t] >> 1) + (unsigned)dw) >> 1;
+          pix = arow[mq][t] + dpix_t + __mul24(ih, p.cv_Win) + iw;
+        } else {
+          pix = arow[mq][t] + dpix;
+        }
+        const bool ok = (cv_ok[mq][t] >> tap) & 1u;
+        const uint64_t src = (ok ? abase : zbase) + (uint64_t)(ok ? (unsigned)pix : 0u) * row_b + swz[t];
+        __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(dst + t * 1024), 16, 0, 0);
+      }
+      return;
+    }
 #pragma unroll
     for (int t = 0; t < 2; ++t)
       __builtin_amdgcn_global_load_lds((gbl_void*)(base + ((unsigned)arow[mq][t] * ldb + swz[t])), (lds_void*)(dst + t * 1024),
@@ -824,6 +878,10 @@ __global__ __launch_bounds__(512) void gemm8p_nt_kernel(const GemmParams p) {
 
   // ---- prologue: the steady-state issue order A-mq0, W-nq0, W-nq1, A-mq1 of tile 0, then A-mq0, W-nq0 of tile 1 ----
   auto prologue = [&]() {
+    if constexpr (CONV) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m) { cvc_chunk[m] = 0; cvc_dw[m] = 0; cvc_dh[m] = 0; cvc_dt[m] = 0; cvc_tap[m] = 0; }
+    }
     stage_a(C0{}, 0, 0);
     stage_w(C0{}, 0, 0);
     stage_w(C1{}, 0, 0);
@@ -1007,6 +1065,31 @@ static int launch_gemm8p(GemmParams& p, hipStream_t s) {
   return LCV_OK;
 }
 
+// The convolution form of the 8-phase kernel (N >= 192 stages of the VAE): persistent, no split-K tail.
+template <int EPI>
+static int launch_conv8p(GemmParams& p, hipStream_t s) {
+  p.tiles_m = (int)((p.M + 255) / 256);
+  p.group_m = 6;
+  p.tiles_n = (int)((p.N + 255) / 256);
+  const size_t lds = 2 * 65536;
+  auto kern = gemm8p_nt_kernel<EPI, true, false, true>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      lcv_set_error("conv3d: cannot raise dynamic LDS to %zu", lds);
+      return LCV_EDEVICE;
+    }
+    attr_set = true;
+  }
+  const int ntiles = p.tiles_m * p.tiles_n;
+  p.vid_begin = 0; p.vid_count = ntiles; p.splitk = 1; p.nk_split = 0; p.ws = nullptr;
+  unsigned grid = (unsigned)ntiles;
+  if (grid > 256) grid = 256;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, p);
+  LCV_LAUNCH_CHECK("conv8p_igemm");
+  return LCV_OK;
+}
+
 #include "gemm4w.h"
 #include "gemm4p.h"
 
@@ -1123,6 +1206,14 @@ static int dispatch_tile(GemmParams& p, hipStream_t s) {
 
 template <int EPI>
 static int dispatch_conv(GemmParams& p, hipStream_t s) {
+  // wide stages: the 8-phase kernel when its pipeline has K tiles to fill (>= 2)
+  // wide stages.  LCV_CONV_8P=1: the 8-phase kernel with the gather in its A stream - bit-identical to the two-stage kernel and
+  // no faster on the VAE's shapes (802 vs 816 TF/s on 192 -> 192 at 360 x 640), so it stays opt-in.
+  const char* e8 = getenv("LCV_CONV_8P");
+  if (p.N >= 192 && p.nk1 >= 2 && e8 && e8[0] == '1') return launch_conv8p<EPI>(p, s);
+  // Cout = 192 / 384: 192-column tiles instead of 256-column tiles of which a quarter multiplies padding
+  const char* e192 = getenv("LCV_CONV_N192");
+  if (p.N >= 192 && p.N % 192 == 0 && !(e192 && e192[0] == '0')) return launch_gemm16<256, 192, 2, 4, EPI, true>(p, s);
   if (p.N >= 192) return launch_gemm16<256, 256, 2, 4, EPI, true>(p, s);
   return launch_gemm16<128, 128, 2, 2, EPI, true>(p, s);
 }
@@ -1210,7 +1301,10 @@ static int conv3d_impl(const void* x, const void* w, const void* bias, const voi
     if (p.N <= 16) return resid ? launch_conv_rows<8, 1, 2, 1, LCV_EPI_GATE_RESIDUAL>(p, s) : launch_conv_rows<8, 1, 2, 1, LCV_EPI_NONE>(p, s);
     return resid ? launch_conv_rows<4, 2, 4, 3, LCV_EPI_GATE_RESIDUAL>(p, s) : launch_conv_rows<4, 2, 4, 3, LCV_EPI_NONE>(p, s);
   }
-  g_last_conv_kernel = p.N >= 192 ? "conv16_igemm<256x256>" : "conv16_igemm<128x128>";
+  { const char* e8 = getenv("LCV_CONV_8P"); const char* e192 = getenv("LCV_CONV_N192");
+    g_last_conv_kernel = p.N < 192 ? "conv16_igemm<128x128>"
+                         : (p.nk1 >= 2 && e8 && e8[0] == '1') ? "conv8p_igemm<256x256>"
+                         : (p.N % 192 == 0 && !(e192 && e192[0] == '0')) ? "conv16_igemm<256x192>" : "conv16_igemm<256x256>"; }
   if (resid) return dispatch_conv<LCV_EPI_GATE_RESIDUAL>(p, s);
   return dispatch_conv<LCV_EPI_NONE>(p, s);
 }

@@ -29,7 +29,9 @@ def test_conv_kernel_against_conv3d():
     from longcat_video.modules.vae_wan import AutoencoderKLWan, _Conv
     vae = AutoencoderKLWan(base_dim=16, z_dim=4, device="cuda", dtype=BF16)
     g = torch.Generator().manual_seed(0)
-    for (ci, co, k, up) in ((64, 96, (3, 3, 3), False), (128, 64, (3, 3), True), (64, 128, (3, 1, 1), False), (64, 3, (3, 3, 3), False)):
+    # Cout >= 192: the wide tiles (see the next test for many tiles)
+    for (ci, co, k, up) in ((64, 96, (3, 3, 3), False), (128, 64, (3, 3), True), (64, 128, (3, 1, 1), False), (64, 3, (3, 3, 3), False),
+                            (64, 192, (3, 3, 3), False), (128, 256, (3, 3), True), (192, 384, (1, 1, 1), False)):
         conv = _Conv(ci, co, k, device="cuda", dtype=BF16)
         w = torch.randn((co, ci) + k, generator=g) * (ci * 9) ** -0.5
         b = torch.randn(co, generator=g) * 0.1
@@ -124,14 +126,65 @@ def test_vae_decode_matches_oracle(T):
     assert got.min() >= -1 and got.max() <= 1
 
 
+@pytest.mark.parametrize("ci,co,k,up,resid", [(192, 192, (3, 3, 3), False, True), (384, 192, (3, 3), True, False), (64, 320, (3, 3, 3), False, False)])
+def test_wide_conv_kernel_many_tiles(ci, co, k, up, resid, monkeypatch):
+    """The wide implicit GEMMs (Cout >= 192) over several hundred 256-pixel tiles with image borders inside tiles: the default
+    (192-column tiles when Cout is a multiple of 192), the opt-in 8-phase form (LCV_CONV_8P=1; more than one tile per CU of its
+    persistent grid) and the 256-column two-stage kernel - the same products in the same K order, so bit for bit - and torch."""
+    import torch.nn.functional as F
+    from longcat_video.modules.vae_wan import AutoencoderKLWan, _Conv
+    from lcv_hip import lib as _lib
+    vae = AutoencoderKLWan(base_dim=16, z_dim=4, device="cuda", dtype=BF16)
+    g = torch.Generator().manual_seed(21)
+    T, H, W = 3, 150, 203                       # 91350 pixels = 357 tiles (x 4 with the upsample)
+    conv = _Conv(ci, co, k, device="cuda", dtype=BF16)
+    taps = 1
+    for v in k:
+        taps *= v
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn((co, ci) + k, generator=g) * (ci * taps) ** -0.5)
+        conv.bias.copy_(torch.randn(co, generator=g) * 0.1)
+    x = torch.randn(1, T, H, W, ci, generator=g).to(BF16)
+    Ho, Wo = (2 * H, 2 * W) if up else (H, W)
+    r = None
+    if resid:
+        r = torch.zeros(1, T, Ho, Wo, (co + 63) // 64 * 64, dtype=BF16)
+        r[..., :co] = torch.randn(1, T, Ho, Wo, co, generator=g).to(BF16)
+    run = lambda: vae._conv(x.cuda(), conv, resid=None if r is None else r.cuda(), up2x=up)
+    got_full = run()                                                    # the default: 192- or 256-column tiles
+    assert _lib.load().lcv_conv3d_last_kernel().decode() == ("conv16_igemm<256x192>" if co % 192 == 0 else "conv16_igemm<256x256>")
+    monkeypatch.setenv("LCV_CONV_8P", "1")
+    p8 = run()
+    assert _lib.load().lcv_conv3d_last_kernel().decode().startswith("conv8p")
+    monkeypatch.delenv("LCV_CONV_8P")
+    monkeypatch.setenv("LCV_CONV_N192", "0")
+    old = run()
+    assert _lib.load().lcv_conv3d_last_kernel().decode() == "conv16_igemm<256x256>"
+    monkeypatch.delenv("LCV_CONV_N192")
+    assert torch.equal(got_full, old) and torch.equal(p8, old)
+    got = got_full[..., :co].float().cpu()
+    xn = x.float().permute(0, 4, 1, 2, 3)
+    wf, bf = conv.weight.float().cpu(), conv.bias.float().cpu()
+    if len(k) == 2:
+        y = xn.permute(0, 2, 1, 3, 4).reshape(T, ci, H, W)
+        if up:
+            y = F.interpolate(y, scale_factor=(2.0, 2.0), mode="nearest-exact")
+        ref = F.conv2d(y, wf, bf, padding=1).view(1, T, co, Ho, Wo).permute(0, 1, 3, 4, 2)
+    else:
+        y = F.pad(xn, (k[2] // 2, k[2] // 2, k[1] // 2, k[1] // 2, k[0] - 1, 0))
+        ref = F.conv3d(y, wf, bf).permute(0, 2, 3, 4, 1)
+    if resid:
+        ref = r[..., :co].float() + ref.to(BF16).float()
+    assert rel_l2(got, ref) < 3e-3
+
+
 def test_strided_conv_kernel_against_torch():
     """The encoder's two downsampling convs: ZeroPad2d((0,1,0,1)) + 3x3 stride 2 per frame, and (3,1,1) stride 2 in time."""
     import torch.nn.functional as F
     from longcat_video.modules.vae_wan import AutoencoderKLWan, _Conv
     vae = AutoencoderKLWan(base_dim=16, z_dim=4, device="cuda", dtype=BF16)
     g = torch.Generator().manual_seed(1)
-    ci = co = 64
-    for (H, W) in ((6, 10), (7, 9)):
+    for (H, W, ci, co) in ((6, 10, 64, 64), (7, 9, 64, 64), (32, 45, 128, 192)):     # the last: wide tiles, several of them
         conv = _Conv(ci, co, (3, 3), device="cuda", dtype=BF16)
         with torch.no_grad():
             conv.weight.copy_(torch.randn((co, ci, 3, 3), generator=g) * (ci * 9) ** -0.5); conv.bias.copy_(torch.randn(co, generator=g) * 0.1)
@@ -141,6 +194,7 @@ def test_strided_conv_kernel_against_torch():
         ref = F.conv2d(y, conv.weight.float().cpu(), conv.bias.float().cpu(), stride=2)
         assert ref.shape[-2:] == (H // 2, W // 2)
         assert rel_l2(got, ref.view(1, 3, co, H // 2, W // 2).permute(0, 1, 3, 4, 2)) < 3e-3
+    ci = co = 64
     conv = _Conv(ci, co, (3, 1, 1), device="cuda", dtype=BF16)
     with torch.no_grad():
         conv.weight.copy_(torch.randn((co, ci, 3, 1, 1), generator=g) * (ci * 3) ** -0.5); conv.bias.copy_(torch.randn(co, generator=g) * 0.1)
