@@ -3,7 +3,7 @@
 // Why a second convolution kernel.  The implicit-GEMM form above stages, for every tap, the 128 or 256 gathered input rows of
 // its output tile: at 96 channels (the 720p stage of the decoder, the first stage of the encoder) that is a 128 x 128 tile
 // padded from 96 x 96 - 44 % of the MFMA work multiplies zeros - and 32 KB of L2->LDS traffic per 1.2 real MFLOP.  Counters
-// (profiles/r03_conv_pmc.md): MFMA busy 0.32, HBM 0.7 TB/s, L2 hit 0.92, 11.4 TB/s of LDS-DMA fill - the kernel is bound by the
+// (profiles/r02_conv_rows.md): MFMA busy 0.32, HBM 0.7 TB/s, L2 hit 0.92, 11.4 TB/s of LDS-DMA fill - the kernel is bound by the
 // L2->LDS path (guide: 17-19 TB/s from L2 at best), not by the matrix pipe, HBM or address arithmetic.
 //
 // This kernel cuts that traffic 3.6x and drops the padding:
@@ -281,19 +281,23 @@ __global__ __launch_bounds__(512) void conv_rows_kernel(const GemmParams p, cons
       auto multiply = [&]() {
         const unsigned char* sa = smem + abuf * Cfg::A_BYTES + a_frag + dw * 96;
         const unsigned char* sb = smem + bbuf * Cfg::B_BYTES + b_frag;
+        // all 21 fragment reads first: the LDS latency is paid once per sub-step, not once per K block
+        bf16x8 af[3][TM], bfr[3][TN];
 #pragma unroll
         for (int kk = 0; kk < 3; ++kk) {
-          bf16x8 af[TM], bfr[TN];
 #pragma unroll
-          for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * 96 + kk * 16);
+          for (int j = 0; j < TN; ++j) bfr[kk][j] = *reinterpret_cast<const bf16x8*>(sb + j * 16 * 96 + kk * 16);
 #pragma unroll
-          for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(sb + j * 16 * 96 + kk * 16);
+          for (int i = 0; i < TM; ++i) af[kk][i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * 96 + kk * 16);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk)
 #pragma unroll
           for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);  // C^T tile
-        }
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[kk][j], af[kk][i], acc[i][j], 0, 0, 0);  // C^T tile
       };
       if (late) {
         multiply();
