@@ -476,7 +476,12 @@ __device__ __forceinline__ void gemm16_epilogue(const GemmParams& p, f32x4v (&ac
   }
 }
 
-template <int BM, int BN, int WR, int WC, int EPI, bool CONV>
+// NST = 3: a ring of three K-tile buffers, the LDS-DMA of K tile kt + 2 issued at the top of K tile kt and a COUNTED wait (the
+// newest tile may stay in flight across the barrier).  With two buffers the only request in flight is the one issued one
+// K tile earlier.  Tried on the VAE's wide convolutions (1.7 us per K tile for 0.7 us of MFMA work): no gain, so the round trip
+// is not what they wait for (profiles/r02_conv_rows.md); opt-in (LCV_CONV_N192=3).  Same products in the same order:
+// bit-identical to NST = 2.
+template <int BM, int BN, int WR, int WC, int EPI, bool CONV, int NST = 2>
 __global__ __launch_bounds__(WR* WC * 64) void gemm16_nt_kernel(const GemmParams p) {
   using Cfg = GemmCfg<BM, BN, WR, WC>;
   constexpr int TM = BM / WR / 16, TN = BN / WC / 16;
@@ -604,11 +609,22 @@ __global__ __launch_bounds__(WR* WC * 64) void gemm16_nt_kernel(const GemmParams
   const int b_off = (wc * (BN / WC) + r16) * 128;
   const int nk = p.nk1 + p.nk2;
   stage(0, 0);
+  if constexpr (NST == 3) { if (nk > 1) stage(1, 1); }
+  int cbuf = 0, sbuf = 2;                         // NST = 3: buffer being multiplied / staged next
   for (int kt = 0; kt < nk; ++kt) {
-    __syncthreads();
-    if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
-    const unsigned char* sa = smem + (kt & 1) * Cfg::STAGE_BYTES;
+    if constexpr (NST == 3) {
+      // every wave issues IA + IB requests per K tile, so "all but the newest tile" is a compile-time count
+      if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cfg::IA + Cfg::IB) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();               // K tile kt has landed for everyone; everyone is done reading buffer sbuf (K tile kt - 1)
+      if (kt + 2 < nk) stage(kt + 2, sbuf);
+    } else {
+      __syncthreads();
+      if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+    }
+    const unsigned char* sa = smem + (NST == 3 ? cbuf : (kt & 1)) * Cfg::STAGE_BYTES;
     const unsigned char* sb = sa + Cfg::A_BYTES;
+    if constexpr (NST == 3) { cbuf = cbuf == 2 ? 0 : cbuf + 1; sbuf = sbuf == 2 ? 0 : sbuf + 1; }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int ch = ((4 * ks + q) ^ sw) * 16;
@@ -1157,14 +1173,15 @@ static int launch_gemm4w(GemmParams& p, hipStream_t s) {
   return LCV_OK;
 }
 
-template <int BM, int BN, int WR, int WC, int EPI, bool CONV>
+template <int BM, int BN, int WR, int WC, int EPI, bool CONV, int NST = 2>
 static int launch_gemm16(GemmParams& p, hipStream_t s) {
   using Cfg = GemmCfg<BM, BN, WR, WC>;
   p.tiles_m = (int)((p.M + BM - 1) / BM);
   p.group_m = 8;
   p.tiles_n = (int)((p.N + BN - 1) / BN);
-  const size_t lds = 2 * Cfg::STAGE_BYTES;
-  auto kern = gemm16_nt_kernel<BM, BN, WR, WC, EPI, CONV>;
+  const size_t lds = NST * Cfg::STAGE_BYTES;
+  static_assert(NST * Cfg::STAGE_BYTES <= 163840, "gemm16: LDS image");
+  auto kern = gemm16_nt_kernel<BM, BN, WR, WC, EPI, CONV, NST>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
@@ -1231,7 +1248,12 @@ static int dispatch_conv(GemmParams& p, hipStream_t s) {
   if (p.N >= 192 && p.nk1 >= 2 && e8 && e8[0] == '1') return launch_conv8p<EPI>(p, s);
   // Cout = 192 / 384: 192-column tiles instead of 256-column tiles of which a quarter multiplies padding
   const char* e192 = getenv("LCV_CONV_N192");
-  if (p.N >= 192 && p.N % 192 == 0 && !(e192 && e192[0] == '0')) return launch_gemm16<256, 192, 2, 4, EPI, true>(p, s);
+  if (p.N >= 192 && p.N % 192 == 0 && !(e192 && e192[0] == '0')) {
+    // LCV_CONV_N192=3: 192 x 192 tiles on a ring of three buffers with a counted wait - bit-identical and SLOWER (873 vs 919,
+    // 952 vs 1011 TF/s): these kernels do not wait for the round trip of their requests
+    if (e192 && e192[0] == '3') return launch_gemm16<192, 192, 2, 4, EPI, true, 3>(p, s);
+    return launch_gemm16<256, 192, 2, 4, EPI, true>(p, s);
+  }
   if (p.N >= 192) return launch_gemm16<256, 256, 2, 4, EPI, true>(p, s);
   return launch_gemm16<128, 128, 2, 2, EPI, true>(p, s);
 }
@@ -1322,7 +1344,8 @@ static int conv3d_impl(const void* x, const void* w, const void* bias, const voi
   { const char* e8 = getenv("LCV_CONV_8P"); const char* e192 = getenv("LCV_CONV_N192");
     g_last_conv_kernel = p.N < 192 ? "conv16_igemm<128x128>"
                          : (p.nk1 >= 2 && e8 && e8[0] == '1') ? "conv8p_igemm<256x256>"
-                         : (p.N % 192 == 0 && !(e192 && e192[0] == '0')) ? "conv16_igemm<256x192>" : "conv16_igemm<256x256>"; }
+                         : (p.N % 192 == 0 && !(e192 && e192[0] == '0')) ? ((e192 && e192[0] == '3') ? "conv16_igemm<192x192x3>" : "conv16_igemm<256x192>")
+                                                                         : "conv16_igemm<256x256>"; }
   if (resid) return dispatch_conv<LCV_EPI_GATE_RESIDUAL>(p, s);
   return dispatch_conv<LCV_EPI_NONE>(p, s);
 }

@@ -153,6 +153,12 @@ def test_wide_conv_kernel_many_tiles(ci, co, k, up, resid, monkeypatch):
     run = lambda: vae._conv(x.cuda(), conv, resid=None if r is None else r.cuda(), up2x=up)
     got_full = run()                                                    # the default: 192- or 256-column tiles
     assert _lib.load().lcv_conv3d_last_kernel().decode() == ("conv16_igemm<256x192>" if co % 192 == 0 else "conv16_igemm<256x256>")
+    if co % 192 == 0:
+        monkeypatch.setenv("LCV_CONV_N192", "3")                        # opt-in: three-buffer ring, 192 x 192 tiles
+        ring = run()
+        assert _lib.load().lcv_conv3d_last_kernel().decode() == "conv16_igemm<192x192x3>"
+        monkeypatch.delenv("LCV_CONV_N192")
+        assert torch.equal(ring, got_full)
     monkeypatch.setenv("LCV_CONV_8P", "1")
     p8 = run()
     assert _lib.load().lcv_conv3d_last_kernel().decode().startswith("conv8p")
