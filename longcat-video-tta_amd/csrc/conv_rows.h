@@ -29,6 +29,9 @@
 // row (64 c + l) / 6, so one request covers ~11 pixel rows with 96 contiguous bytes each (a first version with four planes of
 // 48-byte rows touched 22-43 cache lines per request).
 #pragma once
+#ifndef CONV_ROWS_LOADERS
+#define CONV_ROWS_LOADERS 8
+#endif
 
 template <int WM, int WN, int TM, int TN>
 struct ConvRowsCfg {
@@ -43,8 +46,6 @@ struct ConvRowsCfg {
   static constexpr int PLB = B_PIECES_PER_PLANE * 1024 + 16;
   static constexpr int B_BYTES = 2 * PLB;
   static constexpr int B_PIECES = 2 * B_PIECES_PER_PLANE;   // 18 / 4
-  static constexpr int IA = (A_PIECES + NW - 1) / NW;   // 7 piece slots per wave
-  static constexpr int IB = (B_PIECES + NW - 1) / NW;   // 3 / 1
   static constexpr int IMAGE_BYTES = 2 * A_BYTES + 3 * B_BYTES;   // 157856
   static constexpr int MAX_STEPS = 32, MAX_SUB = 64;             // table sizes (host-checked against kt * kh * slices, x kw)
   static constexpr int TABLE = (IMAGE_BYTES + 15) / 16 * 16;
@@ -65,21 +66,29 @@ struct ConvRowsTile {          // what the sub-step loop and the epilogue need o
 // the first two taps' weights of the NEXT tile are requested during the last sub-steps of the current one and land while its
 // epilogue runs.
 //
-// The sub-step loop is kept free of index arithmetic.  A first version derived (dt, dh, slice, tap) and the two 64-bit source
-// bases from the sub-step number inside the loop: ~800 executed instructions per 36 MFMAs, most of them scalar divisions and
-// SGPR spill traffic (186 v_readlane per iteration) - phase stamps showed 2.0 us in a "request" of four LDS-DMA instructions and
-// request and MFMA times simply adding up.  Now one wave writes, once per tile, the source base of every step (pixel segment)
-// and sub-step (weights) into a small LDS table - one lane per sub-step, the divisions run 64 wide - and the loop advances
-// cursors over the tables of the current and the next tile.
+// Producer / consumer waves.  The CU's LDS-DMA path fills at ~20-25 B/clk (the rate every LDS-staged kernel of this library
+// tops out at), i.e. ~1600 cycles for the 35 KB of a sub-step, and a wave that issues a request while the path is busy is HELD
+// at that instruction: stamps of an earlier form, where the eight MFMA waves issued their own requests, showed 900-1300 cycles
+// per wave and sub-step inside the 5-7 request instructions, ~1150 in reads + MFMAs, and a sub-step of ~3300 cycles - request
+// and multiply time simply added up, whatever their order.  Now waves 8-11 (one per SIMD) do nothing but requests - they keep
+// the fill path busy and absorb its back-pressure - and waves 0-7 do nothing but fragment reads and MFMAs; one barrier per
+// sub-step hands buffers over (the loaders' counted vmcnt before it says "landed", the MFMA waves' arrival says "consumed").
+//
+// The sub-step loop is kept free of index arithmetic: loader 0 writes, once per tile, the source base of every step (pixel
+// segment) and sub-step (weights) into a small LDS table - one lane per sub-step, the divisions run 64 wide - and the loaders
+// advance cursors over the tables of the current and the next tile.
 template <int WM, int WN, int TM, int TN, int EPI>
-__global__ __launch_bounds__(512) void conv_rows_kernel(const GemmParams p, const int tiles_per_row, const int n_tiles) {
+__global__ __launch_bounds__((8 + CONV_ROWS_LOADERS) * 64) void conv_rows_kernel(const GemmParams p, const int tiles_per_row, const int n_tiles) {
   using Cfg = ConvRowsCfg<WM, WN, TM, TN>;
+  constexpr int NL = CONV_ROWS_LOADERS;                            // loader waves
+  constexpr int LA = (Cfg::A_PIECES + NL - 1) / NL;                // 13 piece slots of the pixel segment per loader
+  constexpr int LB = (Cfg::B_PIECES + NL - 1) / NL;                // 5 / 1 of a tap's weights
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
-  const int r16 = lane & 15, q = lane >> 4;
+  const bool loader = wave >= Cfg::NW;
+  const int lw = wave - Cfg::NW;                                   // loader index (loaders only)
   const int kw = p.cv_kw;
 
   // this workgroup's tiles: first + k * stride while < last
@@ -95,15 +104,15 @@ __global__ __launch_bounds__(512) void conv_rows_kernel(const GemmParams p, cons
   if (tile_next >= tile_end) return;                             // (whole workgroup)
 
   // ---- per-tile plan ----
-  // a_off: where each lane's LDS-DMA pieces of the pixel segment come from, relative to the start of the input image row
-  // (2^31: outside - the buffer range check returns zeros).  Piece slot t of this wave is piece g = 8 t + wave; unit (g % 25) * 64 + lane of plane g / 25
-  // = 16-byte block u % 6 of staged row u / 6.
-  // Tables (LDS, per tile parity): tab_a[step] = address of channel slice cs of input image row (t0 + dt, (h0 + dh) >> up),
-  // tab_b[sub-step] = address of w[0][tap][96 cs]; steps enumerate the (dt, dh) taps that read inside the tensor (ranges, since
-  // padding is in front in t, symmetric in h, and the stride is 1) times the channel slices.
+  // Every wave: the scalars (steps, sub-steps, where the tile's rows are).  Loaders: a_off = where each lane's LDS-DMA pieces
+  // of the pixel segment come from, relative to the start of the input image row (2^31: outside - the buffer range check
+  // returns zeros); piece slot t of loader l is piece g = l + 4 t = unit (g % 25) * 64 + lane of plane g / 25 = 16-byte block
+  // u % 6 of staged row u / 6.  Loader 0: the tables (LDS, per tile parity): tab_a[step] = address of channel slice cs of input
+  // image row (t0 + dt, (h0 + dh) >> up), tab_b[sub-step] = address of w[0][tap][96 cs]; steps enumerate the (dt, dh) taps
+  // that read inside the tensor (ranges: padding is in front in t, symmetric in h, the stride is 1) times the channel slices.
   auto tab_a = [&](int parity, int i) { return reinterpret_cast<uint64_t*>(smem + Cfg::TABLE + parity * Cfg::TABLE_BYTES) + i; };
   auto tab_b = [&](int parity, int i) { return tab_a(parity, Cfg::MAX_STEPS + i); };
-  auto plan_tile = [&](int pid, int parity, ConvRowsTile& c, unsigned (&a_off)[Cfg::IA]) {
+  auto plan_tile = [&](int pid, int parity, ConvRowsTile& c, unsigned (&a_off)[LA]) {
     const int up = p.cv_up2x ? 1 : 0;
     const int ldx = (int)p.lda, ncs = p.cv_cpt;
     const int wt = pid % tiles_per_row;
@@ -123,10 +132,11 @@ __global__ __launch_bounds__(512) void conv_rows_kernel(const GemmParams p, cons
     const int ndh = dh_hi - dh_lo;
     c.nsteps = (dt_hi - dt_lo) * ndh * ncs;
     c.nsub = c.nsteps * kw;
+    if (!loader) return;
     const int wbound = p.cv_Win << up;
 #pragma unroll
-    for (int t = 0; t < Cfg::IA; ++t) {
-      const int g = t * Cfg::NW + wave;
+    for (int t = 0; t < LA; ++t) {
+      const int g = t * NL + lw;
       const int plane = g / Cfg::A_PIECES_PER_PLANE;
       const int u = (g - plane * Cfg::A_PIECES_PER_PLANE) * 64 + lane;
       const int row = u / 6, blk = u - row * 6;
@@ -134,7 +144,7 @@ __global__ __launch_bounds__(512) void conv_rows_kernel(const GemmParams p, cons
       const bool ok = g < Cfg::A_PIECES && row < Cfg::BM + kw - 1 && uu >= 0 && uu < wbound;
       a_off[t] = ok ? (unsigned)(((uu >> up) * ldx + plane * 48 + blk * 8) * 2) : 0x80000000u;   // outside: past any num_records
     }
-    if (wave == 0) {                                             // lane l: sub-step l
+    if (lw == 0) {                                               // lane l: sub-step l
       if (lane < c.nsub) {
         const int step = lane / kw, dw = lane - step * kw;
         const int cs = step % ncs, r = step / ncs;
@@ -149,80 +159,160 @@ __global__ __launch_bounds__(512) void conv_rows_kernel(const GemmParams p, cons
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // written before this wave's next barrier
     }
   };
-  auto table_entry = [&](const uint64_t* e) {                    // uniform LDS read -> scalar registers
-    const uint64_t v = *e;
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-    return ((uint64_t)hi << 32) | lo;
-  };
-  // weights of one tap: piece g = 8 t + wave, the same unit order over Cout rows (tile-independent)
-  unsigned b_off[Cfg::IB];
+
+  if (loader) {
+    // =========================== loader waves ===========================
+    auto table_entry = [&](const uint64_t* e) {                  // uniform LDS read -> scalar registers
+      const uint64_t v = *e;
+      const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+      return ((uint64_t)hi << 32) | lo;
+    };
+    // weights of one tap: piece g = l + 4 t, the same unit order over Cout rows (tile-independent)
+    unsigned b_off[LB];
 #pragma unroll
-  for (int t = 0; t < Cfg::IB; ++t) {
-    const int g = t * Cfg::NW + wave;
-    const int plane = g / Cfg::B_PIECES_PER_PLANE;
-    const int u = (g - plane * Cfg::B_PIECES_PER_PLANE) * 64 + lane;
-    int n = u / 6;
-    const int blk = u - n * 6;
-    if (n > (int)p.N - 1) n = (int)p.N - 1;                      // rows past Cout: any finite data, masked by the epilogue
-    b_off[t] = (unsigned)((n * (int)p.ldw + plane * 48 + blk * 8) * 2);
-  }
-  // Requests are buffer loads into LDS (buffer_load_dwordx4 ... offen lds): a 128-bit resource built from the scalar table
-  // entry, the lane's 32-bit offset from the plan, and the hardware range check as the zero padding - a lane whose offset is
-  // past num_records (the "outside" mark) gets zeros written to its LDS slot.  No vector instruction per piece; the global-load
-  // form needed a 64-bit add, a compare and two selects per piece against a zero page.
-  const int row_bytes = p.cv_Win * (int)p.lda * 2;               // one input image row
-  const int w_bytes = (int)(p.N * p.ldw * 2);
-  auto stage_pixels = [&](uint64_t base, const unsigned (&a_off)[Cfg::IA], int buf, int t_begin, int t_end) {
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, row_bytes, 0x00020000);
-    unsigned char* dst = smem + buf * Cfg::A_BYTES;
-#pragma unroll
-    for (int t = 0; t < Cfg::IA; ++t) {
-      if (t < t_begin || t >= t_end) continue;
-      const int g = t * Cfg::NW + wave;
-      if (g >= Cfg::A_PIECES) continue;                          // wave-uniform
-      const int plane = g / Cfg::A_PIECES_PER_PLANE;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(dst + plane * Cfg::PLA + (g - plane * Cfg::A_PIECES_PER_PLANE) * 1024), 16,
-                                               (int)a_off[t], 0, 0, 0);
-    }
-  };
-  auto stage_weights = [&](uint64_t base, int buf, int t_begin = 0, int t_end = Cfg::IB) {
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, w_bytes, 0x00020000);
-    unsigned char* dst = smem + 2 * Cfg::A_BYTES + buf * Cfg::B_BYTES;
-#pragma unroll
-    for (int t = 0; t < Cfg::IB; ++t) {
-      if (t < t_begin || t >= t_end) continue;
-      const int g = t * Cfg::NW + wave;
-      if (g >= Cfg::B_PIECES) continue;                          // wave-uniform
+    for (int t = 0; t < LB; ++t) {
+      const int g = t * NL + lw;
       const int plane = g / Cfg::B_PIECES_PER_PLANE;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(dst + plane * Cfg::PLB + (g - plane * Cfg::B_PIECES_PER_PLANE) * 1024), 16,
-                                               (int)b_off[t], 0, 0, 0);
+      const int u = (g - plane * Cfg::B_PIECES_PER_PLANE) * 64 + lane;
+      int n = u / 6;
+      const int blk = u - n * 6;
+      if (n > (int)p.N - 1) n = (int)p.N - 1;                    // rows past Cout: any finite data, masked by the epilogue
+      b_off[t] = (unsigned)((n * (int)p.ldw + plane * 48 + blk * 8) * 2);
     }
-  };
-
-  // ---- pipeline: loads run TWO sub-steps ahead of the MFMAs ----
-  // Weights of sub-step j + 2 and the next pixel segment (its pieces spread over the first two taps of the current step) are
-  // requested at sub-step j, into a third weight buffer; the wait at the top of a sub-step is counted: this wave's requests of
-  // the previous sub-step may stay in flight, except a segment part that completes the segment the coming sub-step starts on
-  // (those were issued before the weights, so they are the older ones).
-  int nb_wave = 0;
+    // Requests are buffer loads into LDS (buffer_load_dwordx4 ... offen lds): a 128-bit resource built from the scalar table
+    // entry, the lane's 32-bit offset from the plan, and the hardware range check as the zero padding - a lane whose offset
+    // is past num_records (the "outside" mark) gets zeros written to its LDS slot.  No vector instruction per piece.
+    const int row_bytes = p.cv_Win * (int)p.lda * 2;             // one input image row
+    const int w_bytes = (int)(p.N * p.ldw * 2);
+    auto stage_pixels = [&](uint64_t base, const unsigned (&a_off)[LA], int buf, int t_begin, int t_end) {
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, row_bytes, 0x00020000);
+      unsigned char* dst = smem + buf * Cfg::A_BYTES;
 #pragma unroll
-  for (int t = 0; t < Cfg::IB; ++t) nb_wave += (t * Cfg::NW + wave < Cfg::B_PIECES) ? 1 : 0;
-  // segment parts: pieces [0, 4) with the first tap, [4, 7) with the second (kw < 3: everything with the first)
-  const int na_part0 = kw >= 3 ? 4 : ((Cfg::IA - 1) * Cfg::NW + wave < Cfg::A_PIECES ? Cfg::IA : Cfg::IA - 1);
-  const int na_part1 = kw >= 3 ? ((Cfg::IA - 1) * Cfg::NW + wave < Cfg::A_PIECES ? Cfg::IA - 4 : Cfg::IA - 5) : 0;
-  auto wait_allow = [&](int n) {       // s_waitcnt takes an immediate
-    switch (n) {
-      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-      case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-      case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-      case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-      case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-      default: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-    }
-  };
+      for (int t = 0; t < LA; ++t) {
+        if (t < t_begin || t >= t_end) continue;
+        const int g = t * NL + lw;
+        if (g >= Cfg::A_PIECES) continue;                        // wave-uniform
+        const int plane = g / Cfg::A_PIECES_PER_PLANE;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(dst + plane * Cfg::PLA + (g - plane * Cfg::A_PIECES_PER_PLANE) * 1024), 16,
+                                                 (int)a_off[t], 0, 0, 0);
+      }
+    };
+    auto stage_weights = [&](uint64_t base, int buf) {
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, w_bytes, 0x00020000);
+      unsigned char* dst = smem + 2 * Cfg::A_BYTES + buf * Cfg::B_BYTES;
+#pragma unroll
+      for (int t = 0; t < LB; ++t) {
+        const int g = t * NL + lw;
+        if (g >= Cfg::B_PIECES) continue;                        // wave-uniform
+        const int plane = g / Cfg::B_PIECES_PER_PLANE;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(dst + plane * Cfg::PLB + (g - plane * Cfg::B_PIECES_PER_PLANE) * 1024), 16,
+                                                 (int)b_off[t], 0, 0, 0);
+      }
+    };
+    // how many requests this loader makes: per tap of weights, and per part of a segment (the segment of the NEXT step is
+    // requested in parts over the sub-steps of the current one: 5 / 4 / 4 piece slots with three taps along w)
+    auto count = [&](int t_begin, int t_end, int pieces) {
+      int n = 0;
+      for (int t = t_begin; t < t_end; ++t) n += (t * NL + lw < pieces) ? 1 : 0;
+      return n;
+    };
+    constexpr int P0 = (LA * 5 + 12) / 13, P1 = P0 + (LA - P0 + 1) / 2, PH = (LA + 1) / 2;   // 5 | 9 of 13 slots; 7 of 13
+    auto part_begin = [&](int dw) { return kw >= 3 ? (dw == 0 ? 0 : dw == 1 ? P0 : dw == 2 ? P1 : LA) : kw == 2 ? (dw == 0 ? 0 : PH) : (dw == 0 ? 0 : LA); };
+    auto part_end = [&](int dw) { return kw >= 3 ? (dw == 0 ? P0 : dw == 1 ? P1 : LA) : kw == 2 ? (dw == 0 ? PH : LA) : LA; };
+    const int nb = count(0, LB, Cfg::B_PIECES);
+    const int na0 = count(part_begin(0), part_end(0), Cfg::A_PIECES), na1 = count(part_begin(1), part_end(1), Cfg::A_PIECES),
+              na2 = count(part_begin(2), part_end(2), Cfg::A_PIECES);
+    auto wait_allow = [&](int n) {     // s_waitcnt takes an immediate; at most LA + LB = 18 requests per sub-step
+      switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+        case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+        case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+        case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+        case 17: asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+      }
+    };
 
+    ConvRowsTile cur, nxt;
+    unsigned a_cur[LA], a_nxt[LA];
+    int par = 0;                                                 // table parity of cur
+    plan_tile(tile_next, 0, cur, a_cur);
+    tile_next += tile_stride;
+    bool has_nxt = tile_next < tile_end;
+    if (has_nxt) plan_tile(tile_next, 1, nxt, a_nxt);
+    else nxt = cur;
+    __builtin_amdgcn_s_barrier();                                // [start] tables visible to the other loaders
+    stage_pixels(table_entry(tab_a(0, 0)), a_cur, 0, 0, LA);
+    stage_weights(table_entry(tab_b(0, 0)), 0);
+    stage_weights(table_entry(tab_b(0, 1)), 1);                  // every tile has >= 2 sub-steps (host-checked)
+    int allow = nb;
+    int abuf = 0;                                                // pixel buffer of the step being multiplied
+    // request cursors: weights of sub-step (current + 2), segment of step (current + 1); `_nx`: the cursor is in the next tile
+    int rb_idx = 2, rb_buf = 2, ra_idx = 1;
+    bool rb_nx = false, ra_nx = false;
+    auto normalize = [&]() {
+      if (!rb_nx && rb_idx >= cur.nsub) { rb_idx -= cur.nsub; rb_nx = true; }
+      if (!ra_nx && ra_idx >= cur.nsteps) { ra_idx -= cur.nsteps; ra_nx = true; }
+    };
+    normalize();
+    for (;;) {
+      int dw = 0;
+      for (int sub = 0; sub < cur.nsub; ++sub) {
+        wait_allow(allow);                                       // this sub-step's images have landed (this loader's part)
+        __builtin_amdgcn_s_barrier();                            // [sub-step] hand-over: landed / consumed
+        int issued = 0, a_issued = 0;
+        if (!ra_nx || has_nxt) {                                 // segment of the next step (older than the weights below)
+          const int tb = part_begin(dw), te = part_end(dw);
+          if (tb < te) {
+            const uint64_t base = table_entry(tab_a(par ^ (ra_nx ? 1 : 0), ra_idx));
+            if (ra_nx) stage_pixels(base, a_nxt, abuf ^ 1, tb, te);
+            else stage_pixels(base, a_cur, abuf ^ 1, tb, te);
+            a_issued = dw == 0 ? na0 : dw == 1 ? na1 : dw == 2 ? na2 : 0;
+            issued = a_issued;
+          }
+        }
+        if (!rb_nx || has_nxt) {
+          stage_weights(table_entry(tab_b(par ^ (rb_nx ? 1 : 0), rb_idx)), rb_buf);
+          issued += nb;
+        }
+        rb_buf = rb_buf == 2 ? 0 : rb_buf + 1;
+        ++rb_idx;
+        const bool step_ends = dw == kw - 1;
+        allow = step_ends ? issued - a_issued : issued;          // next sub-step starts a step: its segment must be complete
+        if (step_ends) { dw = 0; abuf ^= 1; ++ra_idx; } else ++dw;
+        normalize();
+      }
+      if (!has_nxt) break;
+      cur = nxt;
+#pragma unroll
+      for (int t = 0; t < LA; ++t) a_cur[t] = a_nxt[t];
+      par ^= 1;
+      rb_nx = false; ra_nx = false;                              // the cursors were in this tile already
+      tile_next += tile_stride;
+      has_nxt = tile_next < tile_end;
+      if (has_nxt) plan_tile(tile_next, par ^ 1, nxt, a_nxt);
+      normalize();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
+
+  // =========================== MFMA waves ===========================
+  const int wm = wave / WN, wn = wave % WN;
+  const int r16 = lane & 15, q = lane >> 4;
   f32x4v acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -230,92 +320,33 @@ __global__ __launch_bounds__(512) void conv_rows_kernel(const GemmParams p, cons
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
   const int a_frag = (q & 1) * Cfg::PLA + (wm * TM * 16 + r16) * 96 + (q >> 1) * 48;
   const int b_frag = 2 * Cfg::A_BYTES + (q & 1) * Cfg::PLB + (wn * TN * 16 + r16) * 96 + (q >> 1) * 48;
-  const bool late = wave >= 4;
-  ConvRowsTile cur, nxt;
-  unsigned a_cur[Cfg::IA], a_nxt[Cfg::IA];
-  int par = 0;                                                   // table parity of cur
-  plan_tile(tile_next, 0, cur, a_cur);
+  ConvRowsTile cur;
+  unsigned unused_plan[LA];
+  plan_tile(tile_next, 0, cur, unused_plan);
   tile_next += tile_stride;
-  bool has_nxt = tile_next < tile_end;
-  if (has_nxt) plan_tile(tile_next, 1, nxt, a_nxt);
-  else nxt = cur;
-  __syncthreads();                                               // tables visible
-  stage_pixels(table_entry(tab_a(0, 0)), a_cur, 0, 0, Cfg::IA);
-  stage_weights(table_entry(tab_b(0, 0)), 0);
-  stage_weights(table_entry(tab_b(0, 1)), 1);                    // every tile has >= 2 sub-steps (host-checked)
-  int allow = nb_wave;
+  __builtin_amdgcn_s_barrier();                                  // [start]
   int abuf = 0, bbuf = 0;                                        // buffers of the step / sub-step being multiplied
-  // request cursors: weights of sub-step (current + 2), segment of step (current + 1); `_nx`: the cursor is in the next tile
-  int rb_idx = 2, rb_buf = 2, ra_idx = 1;
-  bool rb_nx = false, ra_nx = false;
-  auto normalize = [&]() {
-    if (!rb_nx && rb_idx >= cur.nsub) { rb_idx -= cur.nsub; rb_nx = true; }
-    if (!ra_nx && ra_idx >= cur.nsteps) { ra_idx -= cur.nsteps; ra_nx = true; }
-  };
-  normalize();
-
   for (;;) {
     int dw = 0;
     for (int sub = 0; sub < cur.nsub; ++sub) {
-      wait_allow(allow);                                         // this sub-step's images have landed (this wave's part)
-      __builtin_amdgcn_s_barrier();                              // ... everyone's; and all waves are done with the sub-step before
-      // The two waves of a SIMD (w, w + 4) run the two halves of a sub-step - request, multiply - in opposite order: a wave is
-      // held 100-200 cycles at the issue of every LDS-DMA instruction, and its MFMAs queue behind that in program order.
-      // (Dealing the requests out between the K blocks' MFMAs of the same wave, with all 21 fragment reads up front, was slower:
-      // 3.5 vs 3.2 ms.)
-      int issued = 0, a_issued = 0;
-      auto request = [&]() {
-        if (dw < 2 && (!ra_nx || has_nxt)) {                     // segment of the next step (older than the weights below)
-          const uint64_t base = table_entry(tab_a(par ^ (ra_nx ? 1 : 0), ra_idx));
-          const int tb = dw == 0 ? 0 : (kw >= 3 ? 4 : Cfg::IA), te = dw == 0 ? (kw >= 3 ? 4 : Cfg::IA) : Cfg::IA;
-          if (ra_nx) stage_pixels(base, a_nxt, abuf ^ 1, tb, te);
-          else stage_pixels(base, a_cur, abuf ^ 1, tb, te);
-          a_issued = dw == 0 ? na_part0 : na_part1;
-          issued = a_issued;
-        }
-        if (!rb_nx || has_nxt) {
-          stage_weights(table_entry(tab_b(par ^ (rb_nx ? 1 : 0), rb_idx)), rb_buf);
-          issued += nb_wave;
-        }
-      };
-      auto multiply = [&]() {
-        const unsigned char* sa = smem + abuf * Cfg::A_BYTES + a_frag + dw * 96;
-        const unsigned char* sb = smem + bbuf * Cfg::B_BYTES + b_frag;
-        // all 21 fragment reads first: the LDS latency is paid once per sub-step, not once per K block
-        bf16x8 af[3][TM], bfr[3][TN];
+      __builtin_amdgcn_s_barrier();                              // [sub-step] this sub-step's images have landed
+      const unsigned char* sa = smem + abuf * Cfg::A_BYTES + a_frag + dw * 96;
+      const unsigned char* sb = smem + bbuf * Cfg::B_BYTES + b_frag;
 #pragma unroll
-        for (int kk = 0; kk < 3; ++kk) {
+      for (int kk = 0; kk < 3; ++kk) {
+        bf16x8 af[TM], bfr[TN];
 #pragma unroll
-          for (int j = 0; j < TN; ++j) bfr[kk][j] = *reinterpret_cast<const bf16x8*>(sb + j * 16 * 96 + kk * 16);
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * 96 + kk * 16);
 #pragma unroll
-          for (int i = 0; i < TM; ++i) af[kk][i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * 96 + kk * 16);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+        for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(sb + j * 16 * 96 + kk * 16);
 #pragma unroll
-        for (int kk = 0; kk < 3; ++kk)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[kk][j], af[kk][i], acc[i][j], 0, 0, 0);  // C^T tile
-      };
-      if (late) {
-        multiply();
-        __builtin_amdgcn_sched_barrier(0);
-        request();
-      } else {
-        request();
-        __builtin_amdgcn_sched_barrier(0);
-        multiply();
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);  // C^T tile
       }
-      // advance: buffers, cursors
       bbuf = bbuf == 2 ? 0 : bbuf + 1;
-      rb_buf = rb_buf == 2 ? 0 : rb_buf + 1;
-      ++rb_idx;
-      const bool step_ends = dw == kw - 1;
-      allow = step_ends ? issued - a_issued : issued;            // next sub-step starts a step: its segment must be complete
-      if (step_ends) { dw = 0; abuf ^= 1; ++ra_idx; } else ++dw;
-      normalize();
+      if (dw == kw - 1) { dw = 0; abuf ^= 1; } else ++dw;
     }
     // rows of this tile are output pixels row_begin + w0 + r; those past the end of the image row do not exist
     {
@@ -323,23 +354,14 @@ __global__ __launch_bounds__(512) void conv_rows_kernel(const GemmParams p, cons
       pe.M = cur.row_begin + p.cv_W;
       gemm16_epilogue<TM, TN, EPI>(pe, acc, cur.row_begin + cur.w0 + wm * TM * 16, wn * TN * 16, r16, q);
     }
-    if (!has_nxt) break;
-    cur = nxt;
-#pragma unroll
-    for (int t = 0; t < Cfg::IA; ++t) a_cur[t] = a_nxt[t];
-    par ^= 1;
-    rb_nx = false; ra_nx = false;                                // the cursors were in this tile already
+    if (tile_next >= tile_end) break;
+    plan_tile(tile_next, 0, cur, unused_plan);
     tile_next += tile_stride;
-    has_nxt = tile_next < tile_end;
-    if (has_nxt) plan_tile(tile_next, par ^ 1, nxt, a_nxt);
-    normalize();
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
-    allow = 0;      // the next tile's first images AND this tile's stores (younger, so a counted wait could not skip them)
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 template <int WM, int WN, int TM, int TN, int EPI>
@@ -361,7 +383,7 @@ static int launch_conv_rows(GemmParams& p, hipStream_t s) {
   int grid = 256;
   { const char* e = getenv("LCV_CONV_ROWS_GRID"); if (e && atoi(e) >= 8) grid = atoi(e) / 8 * 8; }
   if ((int64_t)grid > (n_tiles + 7) / 8 * 8) grid = (int)((n_tiles + 7) / 8 * 8);
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), Cfg::LDS_BYTES, s, p, tiles_per_row, (int)n_tiles);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3((8 + CONV_ROWS_LOADERS) * 64), Cfg::LDS_BYTES, s, p, tiles_per_row, (int)n_tiles);   // 8 MFMA waves + the loaders
   LCV_LAUNCH_CHECK("conv_rows");
   return LCV_OK;
 }
