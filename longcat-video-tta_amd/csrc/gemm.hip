@@ -1239,6 +1239,8 @@ static int dispatch_tile(GemmParams& p, hipStream_t s) {
   return launch_gemm<128, 128, 2, 2, EPI, false>(p, s);
 }
 
+#include "conv_wide.h"
+
 template <int EPI>
 static int dispatch_conv(GemmParams& p, hipStream_t s) {
   // wide stages: the 8-phase kernel when its pipeline has K tiles to fill (>= 2)
@@ -1252,7 +1254,8 @@ static int dispatch_conv(GemmParams& p, hipStream_t s) {
     // LCV_CONV_N192=3: 192 x 192 tiles on a ring of three buffers with a counted wait - bit-identical and SLOWER (873 vs 919,
     // 952 vs 1011 TF/s): these kernels do not wait for the round trip of their requests
     if (e192 && e192[0] == '3') return launch_gemm16<192, 192, 2, 4, EPI, true, 3>(p, s);
-    return launch_gemm16<256, 192, 2, 4, EPI, true>(p, s);
+    if (e192 && e192[0] == '2') return launch_gemm16<256, 192, 2, 4, EPI, true>(p, s);      // every wave stages and multiplies
+    return launch_conv_wide<EPI>(p, s);                                                     // loader waves + MFMA waves
   }
   if (p.N >= 192) return launch_gemm16<256, 256, 2, 4, EPI, true>(p, s);
   return launch_gemm16<128, 128, 2, 2, EPI, true>(p, s);
@@ -1344,7 +1347,7 @@ static int conv3d_impl(const void* x, const void* w, const void* bias, const voi
   { const char* e8 = getenv("LCV_CONV_8P"); const char* e192 = getenv("LCV_CONV_N192");
     g_last_conv_kernel = p.N < 192 ? "conv16_igemm<128x128>"
                          : (p.nk1 >= 2 && e8 && e8[0] == '1') ? "conv8p_igemm<256x256>"
-                         : (p.N % 192 == 0 && !(e192 && e192[0] == '0')) ? ((e192 && e192[0] == '3') ? "conv16_igemm<192x192x3>" : "conv16_igemm<256x192>")
+                         : (p.N % 192 == 0 && !(e192 && e192[0] == '0')) ? ((e192 && e192[0] == '3') ? "conv16_igemm<192x192x3>" : (e192 && e192[0] == '2') ? "conv16_igemm<256x192>" : "conv_wide<256x192>")
                                                                          : "conv16_igemm<256x256>"; }
   if (resid) return dispatch_conv<LCV_EPI_GATE_RESIDUAL>(p, s);
   return dispatch_conv<LCV_EPI_NONE>(p, s);

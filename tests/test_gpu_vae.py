@@ -129,7 +129,7 @@ def test_vae_decode_matches_oracle(T):
 @pytest.mark.parametrize("ci,co,k,up,resid", [(192, 192, (3, 3, 3), False, True), (384, 192, (3, 3), True, False), (64, 320, (3, 3, 3), False, False)])
 def test_wide_conv_kernel_many_tiles(ci, co, k, up, resid, monkeypatch):
     """The wide implicit GEMMs (Cout >= 192) over several hundred 256-pixel tiles with image borders inside tiles: the default
-    (192-column tiles when Cout is a multiple of 192), the opt-in 8-phase form (LCV_CONV_8P=1; more than one tile per CU of its
+    (192-column tiles with loader waves when Cout is a multiple of 192; the same tile without them and on a three-buffer ring), the opt-in 8-phase form (LCV_CONV_8P=1; more than one tile per CU of its
     persistent grid) and the 256-column two-stage kernel - the same products in the same K order, so bit for bit - and torch."""
     import torch.nn.functional as F
     from longcat_video.modules.vae_wan import AutoencoderKLWan, _Conv
@@ -152,13 +152,14 @@ def test_wide_conv_kernel_many_tiles(ci, co, k, up, resid, monkeypatch):
         r[..., :co] = torch.randn(1, T, Ho, Wo, co, generator=g).to(BF16)
     run = lambda: vae._conv(x.cuda(), conv, resid=None if r is None else r.cuda(), up2x=up)
     got_full = run()                                                    # the default: 192- or 256-column tiles
-    assert _lib.load().lcv_conv3d_last_kernel().decode() == ("conv16_igemm<256x192>" if co % 192 == 0 else "conv16_igemm<256x256>")
+    assert _lib.load().lcv_conv3d_last_kernel().decode() == ("conv_wide<256x192>" if co % 192 == 0 else "conv16_igemm<256x256>")
     if co % 192 == 0:
-        monkeypatch.setenv("LCV_CONV_N192", "3")                        # opt-in: three-buffer ring, 192 x 192 tiles
-        ring = run()
-        assert _lib.load().lcv_conv3d_last_kernel().decode() == "conv16_igemm<192x192x3>"
-        monkeypatch.delenv("LCV_CONV_N192")
-        assert torch.equal(ring, got_full)
+        for knob, name in (("2", "conv16_igemm<256x192>"), ("3", "conv16_igemm<192x192x3>")):   # no loader waves; three-buffer ring
+            monkeypatch.setenv("LCV_CONV_N192", knob)
+            other = run()
+            assert _lib.load().lcv_conv3d_last_kernel().decode() == name
+            monkeypatch.delenv("LCV_CONV_N192")
+            assert torch.equal(other, got_full)
     monkeypatch.setenv("LCV_CONV_8P", "1")
     p8 = run()
     assert _lib.load().lcv_conv3d_last_kernel().decode().startswith("conv8p")
