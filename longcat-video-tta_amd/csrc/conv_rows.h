@@ -3,15 +3,16 @@
 // Why a second convolution kernel.  The implicit-GEMM form above stages, for every tap, the 128 or 256 gathered input rows of
 // its output tile: at 96 channels (the 720p stage of the decoder, the first stage of the encoder) that is a 128 x 128 tile
 // padded from 96 x 96 - 44 % of the MFMA work multiplies zeros - and 32 KB of L2->LDS traffic per 1.2 real MFLOP.  Counters
-// (profiles/r02_conv_rows.md): MFMA busy 0.32, HBM 0.7 TB/s, L2 hit 0.92, 11.4 TB/s of LDS-DMA fill - the kernel is bound by the
-// L2->LDS path (guide: 17-19 TB/s from L2 at best), not by the matrix pipe, HBM or address arithmetic.
+// (profiles/r02_conv_rows.md): MFMA busy 0.32, HBM 0.7 TB/s, L2 hit 0.92, 11.4 TB/s of LDS-DMA fill = ~20 B/clk per CU, the rate
+// every LDS-staged kernel of this library tops out at - the kernel is bound by the L2->LDS fill path, not by the matrix pipe,
+// HBM or address arithmetic.
 //
 // This kernel cuts that traffic 3.6x and drops the padding:
 //   * an output tile is 256 consecutive pixels of ONE image row (b, t, h, w0 .. w0+255), all Cout <= 96 channels;
 //   * a step is one (dt, dh, 96-channel slice): the input row segment [w0 - pw, w0 + 256 + kw - 1 - pw) is staged ONCE
 //     (258 pixels x 96 channels) and serves the kw taps of that row - tap dw of output pixel r reads staged pixel r + dw;
-//     row / frame validity of a step is uniform over the tile (skipped steps are never staged), column validity is a
-//     per-lane property of the staging (zero page), so the K loop carries no per-pixel masks at all;
+//     row / frame validity of a step is uniform over the tile (skipped steps are never staged), column validity is the range
+//     check of the buffer load that stages a lane's 16 bytes (outside: zeros), so the K loop carries no per-pixel masks at all;
 //   * the weights of one tap (Cout x 96) are staged per tap, in three buffers beside the double-buffered pixel segment;
 //   * with the folded 2x upsample the segment is staged in UPSAMPLED coordinates (pixel u reads source u >> 1).
 //
