@@ -353,7 +353,10 @@ __global__ __launch_bounds__((8 + CONV_ROWS_LOADERS) * 64) void conv_rows_kernel
     {
       GemmParams pe = p;
       pe.M = cur.row_begin + p.cv_W;
-      gemm16_epilogue<TM, TN, EPI>(pe, acc, cur.row_begin + cur.w0 + wm * TM * 16, wn * TN * 16, r16, q);
+      const int64_t mw = cur.row_begin + cur.w0 + wm * TM * 16, nw = wn * TN * 16;
+      // full tiles: hoisted row pointers and 8-byte loads / stores (the same expressions as the generic form)
+      if (g4_fast_epilogue_ok<EPI, TN, TM>(pe, mw, nw)) g4_fast_epilogue<EPI, TN, TM>(pe, acc, mw, nw, r16, q);
+      else gemm16_epilogue<TM, TN, EPI>(pe, acc, mw, nw, r16, q);
     }
     if (tile_next >= tile_end) break;
     plan_tile(tile_next, 0, cur, unused_plan);

@@ -141,7 +141,10 @@ __global__ __launch_bounds__(1024) void conv_wide_kernel(const GemmParams p) {
     }
     __builtin_amdgcn_s_barrier();                                // [kt + 1]: done with buffer kt & 1; K tile kt + 1 has landed
   }
-  gemm16_epilogue<TM, TN, EPI>(p, acc, m0 + wr * (BM / WR), n0 + wc * (BN / WC), r16, q);
+  // full tiles: hoisted row pointers and 8-byte loads / stores (the same expressions as the generic form, operand for operand)
+  const int64_t mw = m0 + wr * (BM / WR), nw = n0 + wc * (BN / WC);
+  if (g4_fast_epilogue_ok<EPI, TN, TM>(p, mw, nw)) g4_fast_epilogue<EPI, TN, TM>(p, acc, mw, nw, r16, q);
+  else gemm16_epilogue<TM, TN, EPI>(p, acc, mw, nw, r16, q);
 }
 
 template <int EPI>

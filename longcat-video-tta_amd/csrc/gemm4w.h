@@ -66,22 +66,23 @@ __host__ __device__ constexpr int g4_read_slot(int g, int NR, int NG) {
 // the residual row of block i+1 is requested before block i is finished, and every store is a base + immediate.  Same
 // expressions as the generic form, operand for operand: results are bit-identical (tests/test_gpu_kernels.py).  Edge tiles,
 // fp32 output, the GELU / SiLU epilogues and a tile whose rows straddle two latent frames (gate rows differ) take the generic one.
-template <int EPI, int TN>
+// TMB = 16-row blocks per wave (8 in the GEMM kernels, 4 in the row-tile convolution)
+template <int EPI, int TN, int TMB = 8>
 __device__ __forceinline__ bool g4_fast_epilogue_ok(const GemmParams& p, int64_t mw, int64_t nw) {
-  if (p.out_f32 || mw + 128 > p.M || nw + 16 * TN > p.N || (p.ldc & 3) || ((uintptr_t)p.c & 7)) return false;
+  if (p.out_f32 || mw + 16 * TMB > p.M || nw + 16 * TN > p.N || (p.ldc & 3) || ((uintptr_t)p.c & 7)) return false;
   if (p.bias && ((uintptr_t)p.bias & 7)) return false;
   if constexpr (EPI == LCV_EPI_NONE) return true;
   if constexpr (EPI == LCV_EPI_GATE_RESIDUAL) {
     if ((uintptr_t)p.resid & 7) return false;
-    if (p.gate && (((uintptr_t)p.gate & 15) || (p.mod_stride & 3) || mw / p.rows_per_frame != (mw + 127) / p.rows_per_frame)) return false;
+    if (p.gate && (((uintptr_t)p.gate & 15) || (p.mod_stride & 3) || mw / p.rows_per_frame != (mw + 16 * TMB - 1) / p.rows_per_frame)) return false;
     return true;
   }
   if constexpr (EPI == LCV_EPI_SWIGLU) return (TN % 4 == 0) && (!p.resid || (((uintptr_t)p.resid & 7) == 0 && (p.N & 3) == 0));
   return false;
 }
 
-template <int EPI, int TN>
-__device__ __forceinline__ void g4_fast_epilogue(const GemmParams& p, f32x4v (&acc)[8][TN], int64_t mw, int64_t nw, int r16, int q) {
+template <int EPI, int TN, int TMB = 8>
+__device__ __forceinline__ void g4_fast_epilogue(const GemmParams& p, f32x4v (&acc)[TMB][TN], int64_t mw, int64_t nw, int r16, int q) {
   float bv[TN][4];
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
@@ -97,7 +98,7 @@ __device__ __forceinline__ void g4_fast_epilogue(const GemmParams& p, f32x4v (&a
   if constexpr (EPI == LCV_EPI_NONE) {
     bf16_t* crow = (bf16_t*)p.c + (mw + r16) * p.ldc + nw + 4 * q;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < TMB; ++i) {
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         u16x4 o;
@@ -126,8 +127,8 @@ __device__ __forceinline__ void g4_fast_epilogue(const GemmParams& p, f32x4v (&a
 #pragma unroll
     for (int j = 0; j < TN; ++j) rcur[j] = *reinterpret_cast<const u16x4*>(rrow + 16 * j);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      if (i < 7) {
+    for (int i = 0; i < TMB; ++i) {
+      if (i < TMB - 1) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) rnxt[j] = *reinterpret_cast<const u16x4*>(rrow + 16 * p.ldc + 16 * j);
       }
@@ -153,7 +154,7 @@ __device__ __forceinline__ void g4_fast_epilogue(const GemmParams& p, f32x4v (&a
     bf16_t* crow = (bf16_t*)p.c + (mw + r16) * p.ldc + nw / 2 + 4 * q;
     bf16_t* arow = p.resid ? const_cast<bf16_t*>(p.resid) + (mw + r16) * p.N + nw + 4 * q : nullptr;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < TMB; ++i) {
 #pragma unroll
       for (int jb = 0; jb < TN / 4; ++jb)
 #pragma unroll
