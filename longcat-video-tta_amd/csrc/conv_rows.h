@@ -116,13 +116,24 @@ __global__ __launch_bounds__((8 + CONV_ROWS_LOADERS) * 64) void conv_rows_kernel
   auto plan_tile = [&](int pid, int parity, ConvRowsTile& c, unsigned (&a_off)[LA]) {
     const int up = p.cv_up2x ? 1 : 0;
     const int ldx = (int)p.lda, ncs = p.cv_cpt;
-    const int wt = pid % tiles_per_row;
-    int rowid = pid / tiles_per_row;
-    const int ho = rowid % p.cv_H;
-    c.row_begin = (int64_t)rowid * p.cv_W;
-    rowid /= p.cv_H;
-    const int to = rowid % p.cv_T;
-    const int bb = rowid / p.cv_T;
+    // tile sequence: frame index innermost.  The G workgroups of an XCD then work on G consecutive frames of the same row
+    // segment at the same time, and the three dt taps of neighbouring tiles read the same input rows out of that XCD's L2
+    // (with w innermost every input row was fetched from HBM once per dt tap: fetch = 2.6 x the input)
+    int to, wt, ho, bb;
+    if (p.splitk == 0) {
+      to = pid % p.cv_T;
+      int r = pid / p.cv_T;
+      wt = r % tiles_per_row; r /= tiles_per_row;
+      ho = r % p.cv_H;
+      bb = r / p.cv_H;
+    } else {                                                     // LCV_CONV_ROWS_ORDER=w (A/B): w innermost, then h, t
+      wt = pid % tiles_per_row;
+      int r = pid / tiles_per_row;
+      ho = r % p.cv_H; r /= p.cv_H;
+      to = r % p.cv_T;
+      bb = r / p.cv_T;
+    }
+    c.row_begin = ((int64_t)(bb * p.cv_T + to) * p.cv_H + ho) * p.cv_W;
     c.w0 = wt * Cfg::BM;
     const int t0 = to - p.cv_pt, h0 = ho - p.cv_ph;
     const int hb = p.cv_Hin << up;

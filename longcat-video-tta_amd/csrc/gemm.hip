@@ -1340,6 +1340,7 @@ static int conv3d_impl(const void* x, const void* w, const void* bias, const voi
   hipStream_t s = (hipStream_t)stream;
   if (conv_rows_applies(p, Cin)) {
     p.cv_cpt = (int)(Cin / 96);
+    { const char* eo = getenv("LCV_CONV_ROWS_ORDER"); p.splitk = (eo && eo[0] == 'w') ? 1 : 0; }   // tile sequence (conv_rows.h)
     g_last_conv_kernel = p.N <= 16 ? "conv_rows<256x16>" : "conv_rows<256x96>";
     if (p.N <= 16) return resid ? launch_conv_rows<8, 1, 2, 1, LCV_EPI_GATE_RESIDUAL>(p, s) : launch_conv_rows<8, 1, 2, 1, LCV_EPI_NONE>(p, s);
     return resid ? launch_conv_rows<4, 2, 4, 3, LCV_EPI_GATE_RESIDUAL>(p, s) : launch_conv_rows<4, 2, 4, 3, LCV_EPI_NONE>(p, s);
