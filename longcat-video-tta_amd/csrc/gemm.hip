@@ -40,6 +40,7 @@ struct GemmParams {
   // and leaves its fp32 accumulators in `ws` (register order); gemm8p_splitk_reduce_kernel adds the slices and runs the epilogue
   int vid_begin, vid_count, splitk, nk_split;
   float* ws;
+  int fast_epi;                // 8-phase kernel: interior tiles take gemm_fast_epilogue.h (LCV_GEMM_FAST_EPI=0 turns it off)
   // implicit-GEMM convolution mode (channels-last activations [B,Tin,Hin,Win,Cin], rows m = output pixels):
   // K tiles run over (tap, 64-channel chunk); out-of-range taps read a zero page.
   int cv_T, cv_H, cv_W;        // output extent (rows m = ((b*T + t)*H + h)*W + w)
@@ -680,6 +681,8 @@ __device__ unsigned long long* g_gdbg = nullptr;
 #define GSTAMP() do {} while (0)
 #endif
 
+#include "gemm_fast_epilogue.h"
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -707,6 +710,7 @@ __global__ __launch_bounds__(512) void gemm8p_nt_kernel(const GemmParams p) {
   const int wr = wave >> 2, wc = wave & 3;
   const int r16 = lane & 15, q = lane >> 4;
   const int nwg = p.vid_begin + p.vid_count;   // end of this launch's tile range
+  const bool fast_epi = !CONV && p.fast_epi != 0;
   int k_off = 0;                               // first K tile of this work item (split-K tail launches)
   int nk = p.nk1 + p.nk2;                      // >= 2, nk1 >= 2 (host-checked)
   if constexpr (SPLIT) {
@@ -976,7 +980,8 @@ __global__ __launch_bounds__(512) void gemm8p_nt_kernel(const GemmParams p) {
         setup_tile(next);
         prologue();
       }
-      gemm16_epilogue<8, 4, EPI>(p, acc, mw, nw, r16, q);
+      if (fast_epi && g4_fast_epilogue_ok<EPI, 4>(p, mw, nw)) g4_fast_epilogue<EPI, 4>(p, acc, mw, nw, r16, q);
+      else gemm16_epilogue<8, 4, EPI>(p, acc, mw, nw, r16, q);
       if (!more) break;
       vid = next;
 #pragma unroll
@@ -984,7 +989,8 @@ __global__ __launch_bounds__(512) void gemm8p_nt_kernel(const GemmParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
     } else {
-      gemm16_epilogue<8, 4, EPI>(p, acc, mw, nw, r16, q);
+      if (fast_epi && g4_fast_epilogue_ok<EPI, 4>(p, mw, nw)) g4_fast_epilogue<EPI, 4>(p, acc, mw, nw, r16, q);
+      else gemm16_epilogue<8, 4, EPI>(p, acc, mw, nw, r16, q);
       break;
     }
   }
@@ -1068,6 +1074,7 @@ static int launch_gemm8p(GemmParams& p, hipStream_t s) {
   }
   const int ntiles = p.tiles_m * p.tiles_n;
   p.vid_begin = 0; p.vid_count = ntiles; p.splitk = 1; p.nk_split = 0; p.ws = nullptr;
+  { const char* fe = getenv("LCV_GEMM_FAST_EPI"); p.fast_epi = (fe && fe[0] == '0') ? 0 : 1; }
   if (PERSIST && ntiles > 256 && g_gemm_ws != nullptr) {
     const int t = ntiles % 256, nk = p.nk1 + p.nk2;
     const int sk = choose_tail_split(t, nk, g_gemm_ws_bytes);
