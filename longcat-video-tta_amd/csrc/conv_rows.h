@@ -337,7 +337,6 @@ __global__ __launch_bounds__((8 + CONV_ROWS_LOADERS) * 64) void conv_rows_kernel
   plan_tile(tile_next, 0, cur, unused_plan);
   tile_next += tile_stride;
   __builtin_amdgcn_s_barrier();                                  // [start]
-  __builtin_amdgcn_s_setprio(2);                                 // the loaders yield issue slots to these waves
   int abuf = 0, bbuf = 0;                                        // buffers of the step / sub-step being multiplied
   for (;;) {
     int dw = 0;

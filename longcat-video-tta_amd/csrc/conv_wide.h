@@ -123,7 +123,6 @@ __global__ __launch_bounds__(1024) void conv_wide_kernel(const GemmParams p) {
   const int a_off = (wr * (BM / WR) + r16) * 128;
   const int b_off = A_BYTES + (wc * (BN / WC) + r16) * 128;
   __builtin_amdgcn_s_barrier();                                  // [0]
-  __builtin_amdgcn_s_setprio(2);                                 // the loaders' address arithmetic yields issue slots to these waves
   for (int kt = 0; kt < nk; ++kt) {
     const unsigned char* st = smem + (kt & 1) * STAGE_BYTES;
 #pragma unroll
@@ -142,7 +141,6 @@ __global__ __launch_bounds__(1024) void conv_wide_kernel(const GemmParams p) {
     }
     __builtin_amdgcn_s_barrier();                                // [kt + 1]: done with buffer kt & 1; K tile kt + 1 has landed
   }
-  __builtin_amdgcn_s_setprio(0);
   // full tiles: hoisted row pointers and 8-byte loads / stores (the same expressions as the generic form, operand for operand)
   const int64_t mw = m0 + wr * (BM / WR), nw = n0 + wc * (BN / WC);
   if (g4_fast_epilogue_ok<EPI, TN, TM>(p, mw, nw)) g4_fast_epilogue<EPI, TN, TM>(p, acc, mw, nw, r16, q);
