@@ -24,7 +24,7 @@ for f in glob.glob(root + "/**/*kernel_trace.csv", recursive=True):
         t[r["Kernel_Name"][:60]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
 with open(root + "/summary.md", "w") as o:
     for k in sorted(v):
-        if "gemm16" not in k and "conv_rows" not in k: continue
+        if "gemm16" not in k and "conv_rows" not in k and "conv_wide" not in k: continue
         m = {c: sum(x) / len(x) for c, x in v[k].items()}
         ms = sum(t[k]) / len(t[k]); gui = m.get("GRBM_GUI_ACTIVE", 0) / 8; wc = m.get("SQ_WAVE_CYCLES", 1); sb = m.get("SQ_BUSY_CYCLES", 1)
         line = (f"{k}: {ms:.2f} ms busy {m.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / (1024 * gui):.3f} clock {gui / (ms * 1e6):.2f} GHz "
