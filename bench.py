@@ -29,6 +29,7 @@ WORKLOADS = {  # name: (T_lat, h, w, description)
     "K1": (5, 32, 32, "16x256x256 clip (17 frames -> 5 latent frames, 1 280 tokens)"),
     "K2": (13, 60, 104, "49x480p (13 latent frames, 20 280 tokens)"),
     "K3": (13, 90, 160, "49x720p (13 latent frames, 46 800 tokens)"),
+    "K3p": (49, 90, 160, "north_star's literal 49x90x160 latents (49 latent frames = 193 frames at 720p, 176 400 tokens)"),
     "K5": (31, 60, 104, "121x480p long clip (31 latent frames, 48 360 tokens)"),
 }
 MFMA_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
@@ -55,6 +56,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the untimed extras (VAE decode and LoRA-TTA inner-loop step times for the per-video wall clock)")
+    ap.add_argument("--full-tta-leg", action="store_true",
+                    help="also time full-model TTA at the 480p operating point (SURVEY §2.1 #9 marks it out of scope: opt-in since round 3)")
+    ap.add_argument("--no-k3p", action="store_true", help="skip the one secondary CFG step at the literal 49x90x160 size (~45 s)")
     ap.add_argument("--parallelism", default="dp", choices=["dp", "sp"],
                     help="dp: one independent video per GPU (weak scaling, default); sp: ONE video, latent frames sharded "
                          "over the GPUs with an RCCL K/V all-gather per attention layer (strong scaling, config K5)")
@@ -392,18 +396,35 @@ def main():
             secondary[f"{name}_cfg_step_s"] = round((time.perf_counter() - t1) / 2, 4)
             progress(f"secondary {name}: {secondary[f'{name}_cfg_step_s']} s per CFG step")
             assert torch.isfinite(x2).all().item()
+        if not args.no_k3p and args.depth == 48:
+            # north_star's literal shape, once and for the record (the headline stays K3): ONE CFG step at 176 400 tokens, no
+            # separate warm-up (kernels and weight copies are warm; a second ~45 s step would push the default run past its budget)
+            T2, h2, w2, _ = WORKLOADS["K3p"]
+            lat2 = torch.randn((1, 16, T2, h2, w2), generator=g, device=dev, dtype=torch.float32)
+            progress("secondary K3p: one CFG step at 176 400 tokens (~45 s) ...")
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            x2 = pipe.denoise(lat2, pe, pm, ne, nm, num_cond_latents=0, num_inference_steps=args.num_inference_steps,
+                              guidance_scale=args.guidance_scale, start_step=0, stop_step=1)
+            torch.cuda.synchronize()
+            secondary["K3p_cfg_step_s"] = round(time.perf_counter() - t1, 3)
+            secondary["K3p_tokens"] = T2 * (h2 // 2) * (w2 // 2)
+            progress(f"secondary K3p: {secondary['K3p_cfg_step_s']} s per CFG step")
+            assert torch.isfinite(x2).all().item()
+            del lat2, x2
+            torch.cuda.empty_cache()
 
     # ---- extras (outside the timed region, rank 0 of a 1-GPU run): the other two legs of "wall-clock per TTA video" ----
     extras = dict(secondary)
     if world == 1 and not args.no_extras and args.depth == 48:
         import contextlib
         with contextlib.redirect_stdout(sys.stderr):   # stdout carries exactly one JSON line
-            progress("extras 1/3: the reference's 480p operating point (generation + LoRA TTA)")
+            progress("extras 1/2: the reference's 480p operating point (generation + LoRA TTA)")
             ref_point = measure_reference_point(dit, dev, pe, pm, ne, nm)
-            progress("extras 2/3: VAE decode, then 1 + 20 LoRA-TTA inner steps at the bench resolution, then 20 more with early stopping")
+            progress("extras 2/2: VAE decode, then 1 + 20 LoRA-TTA inner steps at the bench resolution, then 20 more with early stopping")
             extras.update(measure_extras(dit, dev, T, h, w, pe, pm))
-            progress("extras 3/3: full-model TTA at the 480p operating point")
-            ref_point.update(measure_full_tta_reference_point(dit, dev, pe, pm))
+            if args.full_tta_leg:
+                progress("extras (opt-in): full-model TTA at the 480p operating point")
+                ref_point.update(measure_full_tta_reference_point(dit, dev, pe, pm))
             progress("extras done")
         extras["reference_operating_point_480p_14c14g"] = {k: (round(v, 2) if isinstance(v, float) else v) for k, v in ref_point.items()}
         # 20 measured inner steps + (50 denoise steps at the measured step time) + measured decode

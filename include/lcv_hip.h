@@ -144,11 +144,13 @@ int lcv_attn_fwd(const void* q, const void* k, const void* v, void* o, float* ls
  * first call): the library picks the body by shape and scale (software-pipelined self-attention body, phase-ordered body,
  * short-key cross-attention body), and bench.py labels its roofline object with what actually ran. */
 const char* lcv_attn_fwd_last_kernel(void);
-/* Backward (two passes, no atomics: dK/dV per 128-key workgroup, dQ per 256-query workgroup; see csrc/attn_bwd.hip).
- * d_o shares o's strides.  delta_ws: fp32 workspace of B*H*(Nq + 2*roundup(Nq, 32)) floats (delta, then the padded
- * -lse*log2(e) / -delta rows the second-form pass A streams into LDS), plus B*H*Nk*256 floats when Nk <= 128 (fp32 partial
- * dK / dV of a query sweep split over workgroups: the 77-key text cross-attention).  accumulate_kv != 0 adds into the existing dk/dv
- * (second region of the conditioning split).  dq/dk/dv are addressed like q/k/v with their own strides. */
+/* Backward (two passes, no atomics, bit-reproducible: dK/dV per 128-key workgroup, dQ per 256-query workgroup; see
+ * csrc/attn_bwd.hip).  d_o shares o's strides.  delta_ws: fp32 workspace of lcv_attn_bwd_ws_floats(B, H, Nq, Nk) floats:
+ * B*H*(Nq + 2*roundup(Nq, 32)) (delta, then the padded -lse*log2(e) / -delta rows the second-form pass A streams into LDS),
+ * plus qsplit*B*H*Nk*256 when the query sweep of a short-key call (Nk <= 128: the 77-key text cross-attention) is split over
+ * workgroups - one fp32 dK / dV slice per split, added in split order by a finishing kernel.  accumulate_kv != 0 adds into the
+ * existing dk/dv (second region of the conditioning split).  dq/dk/dv are addressed like q/k/v with their own strides. */
+int64_t lcv_attn_bwd_ws_floats(int64_t B, int64_t H, int64_t Nq, int64_t Nk);   /* host-only; a size, not a status */
 int lcv_attn_bwd(const void* q, const void* k, const void* v, const void* o,
                  const void* d_o, const float* lse,
                  void* dq, void* dk, void* dv,
@@ -254,8 +256,10 @@ int lcv_fm_noise(const void* x0, const void* eps, const float* sigma, void* out,
                  int64_t B, int64_t per_sample, void* stream);
 /* loss = mean( (pred[:,:,Tc:] - (eps - x0))^2 ) fp32, and dpred = 2/n * diff on the
  * target slice, 0 on the cond slice.  pred fp32 [B,C,T,HW]; eps/x0 bf16 [B,C,Tt,HW].
- * common.py:485-488.  loss_out: fp32 [1] (zero-filled by callee). dpred nullable. */
-int lcv_fm_mse(const float* pred, const void* eps, const void* x0, float* loss_out, float* dpred,
+ * common.py:485-488.  loss_out: fp32 [1]; dpred nullable; ws: fp32 [LCV_FM_MSE_BLOCKS] scratch - the per-workgroup partial sums
+ * are added in a fixed order by a second launch (no atomics: the training loss is the same float on every run). */
+#define LCV_FM_MSE_BLOCKS 1024
+int lcv_fm_mse(const float* pred, const void* eps, const void* x0, float* loss_out, float* dpred, float* ws,
                int64_t B, int64_t C, int64_t T, int64_t Tc, int64_t HW, void* stream);
 /* Per-sample, no-gradient, deterministic form: loss_out[b] = mean over sample b's target slice.  One launch pair scores
  * the early stopper's whole anchor set (sigmas x noise draws batched into ONE forward) where the reference runs one forward

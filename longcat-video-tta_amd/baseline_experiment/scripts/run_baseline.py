@@ -56,6 +56,7 @@ def main(argv=None):
     rank, world, device = R.setup_distributed(args)
     torch.manual_seed(args.seed)
     out_dir = Path(args.output_dir); out_dir.mkdir(parents=True, exist_ok=True)
+    dp.begin_job(str(out_dir), rank)
     t0 = time.time()
     dit, pipe = R.load_components(args, device)
     model_load_time = time.time() - t0
@@ -93,7 +94,9 @@ def main(argv=None):
                    "error": str(ex)}
         rows.append(row)
     total_inference_time = time.time() - t_inf
-    merged = dp.gather_results(rows) if world > 1 else dp.merge_results([rows])
+    took = [r.get("inference_time_s", 0.0) for r in rows]
+    merged = (dp.gather_results(rows, output_dir=str(out_dir), wait_s=dp.merge_wait_seconds(max(took) if took else 0.0, len(rows)))
+              if world > 1 else dp.merge_results([rows]))
     if rank == 0:
         times = [r["inference_time_s"] for r in merged if "inference_time_s" in r]
         with open(out_dir / "per_video_metrics.csv", "w", newline="") as f:
@@ -122,6 +125,8 @@ def main(argv=None):
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
+        if rank == 0 and dp.exit_code_after_merge():
+            sys.exit(dp.exit_code_after_merge())      # summary.json is written, but a peer never delivered its final rows
 
 
 if __name__ == "__main__":

@@ -1,6 +1,7 @@
 // Flash attention backward for the TTA inner loop (dense, non-causal, D = 128, bf16, fp32 accumulate).
 //
-// Two passes, no atomics, bitwise reproducible:
+// Two passes, no atomics anywhere (the split query sweep of the short-key form keeps one fp32 slice per split and adds the
+// slices in a fixed order), bitwise reproducible:
 //   pass A (attn_bwd_dkv_kernel): one workgroup = 4 waves = 128 keys of one (batch, head); each wave keeps
 //          dK^T and dV^T of its 32 keys in 128 accumulator registers while the workgroup sweeps 32-row
 //          query tiles (Q and dO staged in LDS, double-buffered).  S = Q K^T and dP = dO V^T are computed
@@ -36,8 +37,9 @@ struct AttnBwdParams {
   float scale, scale_log2e;
   int accumulate_kv;
   // pass A over FEW key blocks (text cross-attention: 77 keys = one block per head = 32 workgroups for 25 200 queries): the query
-  // tiles are split `qsplit` ways over workgroups, each adds its fp32 dK / dV into kv_part [B, H, Nk, 2, 128] (zeroed by the
-  // launcher), attn_bwd_kv_finish_kernel rounds (and accumulates) into dk / dv
+  // tiles are split `qsplit` ways over workgroups, each STORES its fp32 dK / dV into its own slice kv_part [split][B, H, Nk, 2, 128]
+  // (every element written by exactly one lane: no zero-fill, no atomics), attn_bwd_kv_finish_kernel adds the slices in split
+  // order, rounds (and accumulates) into dk / dv - the same floats on every run
   int qsplit;
   float* kv_part;
 };
@@ -253,19 +255,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdParams p
 
   // ---- epilogue: acc[d][e] = dX^T[dim = 32*d + (e&3) + 8*(e>>2) + 4*h][key = lane & 31] ----
   const int64_t krow = key0 + r;
-  if (p.qsplit > 1) {   // partial sums of this query range: fp32 atomics (a few MB per call), rounded by the finishing kernel
+  if (p.qsplit > 1) {   // partial sums of this query range: plain fp32 stores into this split's slice, added up by the finishing kernel
     if (krow < p.Nk) {
-      float* part = p.kv_part + (((b * p.H + head) * p.Nk + krow) * 2) * 128;
+      float* part = p.kv_part + ((((int64_t)split * gridDim.z + b) * p.H + head) * p.Nk + krow) * 256;
 #pragma unroll
       for (int d = 0; d < 4; ++d)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i) {
+          const int col = 32 * d + 8 * i + 4 * h;
+          f32x4 a, c;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int col = 32 * d + 8 * i + 4 * h + e;
-            atomicAdd(part + col, dkacc[d][4 * i + e]);
-            atomicAdd(part + 128 + col, dvacc[d][4 * i + e]);
-          }
+          for (int e = 0; e < 4; ++e) { a[e] = dkacc[d][4 * i + e]; c[e] = dvacc[d][4 * i + e]; }
+          *reinterpret_cast<f32x4*>(part + col) = a;
+          *reinterpret_cast<f32x4*>(part + 128 + col) = c;
+        }
     }
     return;
   }
@@ -295,7 +298,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdParams p
   }
 }
 
-// kv_part [B, H, Nk, 2, 128] fp32 -> dk / dv bf16 (strided), adding to what is there when accumulate_kv
+// kv_part [qsplit][B, H, Nk, 2, 128] fp32 -> dk / dv bf16 (strided): the slices added in split order (fixed: bit-reproducible),
+// adding to what is there when accumulate_kv
 __global__ __launch_bounds__(256) void attn_bwd_kv_finish_kernel(const AttnBwdParams p, int64_t B) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // one thread per 4 columns of one (b, h, key, k|v) row
   const int64_t total = B * p.H * p.Nk * 2 * 32;
@@ -306,7 +310,12 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_finish_kernel(const AttnBwdPa
   const int64_t key = row % p.Nk, bh = row / p.Nk;
   const int head = (int)(bh % p.H);
   const int64_t b = bh / p.H;
-  const f32x4 v = *reinterpret_cast<const f32x4*>(p.kv_part + i * 4);
+  f32x4 v = *reinterpret_cast<const f32x4*>(p.kv_part + i * 4);
+  for (int sp = 1; sp < p.qsplit; ++sp) {
+    const f32x4 w = *reinterpret_cast<const f32x4*>(p.kv_part + ((int64_t)sp * total + i) * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] += w[e];
+  }
   bf16_t* dst = which ? p.dv + b * p.dv_sb + key * p.dv_sn + (int64_t)head * p.dv_sh + 4 * c4
                       : p.dk + b * p.dk_sb + key * p.dk_sn + (int64_t)head * p.dk_sh + 4 * c4;
   float o[4] = {v[0], v[1], v[2], v[3]};
@@ -495,6 +504,27 @@ int attn_bwd_dkv2_launch(const void* q, const void* k, const void* v, const void
                          int64_t v_sh, int64_t o_sb, int64_t o_sn, int64_t o_sh, int64_t dk_sb, int64_t dk_sn, int64_t dk_sh,
                          int64_t dv_sb, int64_t dv_sn, int64_t dv_sh, float scale, hipStream_t s);
 
+// few key blocks, many query tiles (the text cross-attention): split the query sweep so that the launch fills the chip
+static int attn_bwd_qsplit(int64_t B, int64_t H, int64_t Nq, int64_t Nk) {
+  const int64_t kblocks = (Nk + 127) / 128, nt = (Nq + 31) / 32;
+  int qsplit = 1;
+  if (Nk <= 128 && kblocks * H * B < 256 && nt >= 64) {
+    qsplit = (int)(512 / (kblocks * H * B));
+    if (qsplit > nt / 16) qsplit = (int)(nt / 16);
+    if (qsplit > 64) qsplit = 64;
+  }
+  return qsplit < 1 ? 1 : qsplit;
+}
+
+// floats of `delta_ws` a call of lcv_attn_bwd with these sizes needs (host-only; a size, not a status)
+extern "C" int64_t lcv_attn_bwd_ws_floats(int64_t B, int64_t H, int64_t Nq, int64_t Nk) {
+  if (B <= 0 || H <= 0 || Nq < 0 || Nk <= 0) return 0;
+  int64_t n = B * H * (Nq + 2 * ((Nq + 31) / 32 * 32));
+  const int qs = attn_bwd_qsplit(B, H, Nq, Nk);
+  if (qs > 1) n += (int64_t)qs * B * H * Nk * 256;
+  return n;
+}
+
 extern "C" int lcv_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o,
                             const float* lse, void* dq, void* dk, void* dv, float* delta_ws, int accumulate_kv,
                             int64_t B, int64_t H, int64_t Nq, int64_t Nk, int64_t q_sb, int64_t q_sn,
@@ -538,23 +568,12 @@ extern "C" int lcv_attn_bwd(const void* q, const void* k, const void* v, const v
     if (rc != LCV_OK) return rc;
   } else {
     const size_t lds = 2 * (2 * 32 * 256 + 2 * 32 * 4);
-    const int64_t kblocks = (Nk + 127) / 128, nt = (Nq + 31) / 32;
-    // few key blocks, many query tiles (the text cross-attention): split the query sweep so that the launch fills the chip
-    int qsplit = 1;
-    if (Nk <= 128 && kblocks * H * B < 256 && nt >= 64) {
-      qsplit = (int)(512 / (kblocks * H * B));
-      if (qsplit > nt / 16) qsplit = (int)(nt / 16);
-      if (qsplit > 64) qsplit = 64;
-    }
+    const int64_t kblocks = (Nk + 127) / 128;
+    const int qsplit = attn_bwd_qsplit(B, H, Nq, Nk);
     p.qsplit = qsplit;
     p.kv_part = nullptr;
-    if (qsplit > 1) {
-      p.kv_part = delta_ws + B * H * (Nq + 2 * ((Nq + 31) / 32 * 32));      // behind the delta / row-constant rows (lcv_hip.h)
-      if (hipMemsetAsync(p.kv_part, 0, (size_t)(B * H * Nk * 256 * 4), s) != hipSuccess) {
-        lcv_set_error("attn_bwd: cannot clear the partial-sum workspace");
-        return LCV_EDEVICE;
-      }
-    }
+    if (qsplit > 1)        // behind the delta / row-constant rows (lcv_attn_bwd_ws_floats); every slice element is stored before it is read
+      p.kv_part = delta_ws + B * H * (Nq + 2 * ((Nq + 31) / 32 * 32));
     hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)(kblocks * qsplit), (unsigned)H, (unsigned)B), dim3(256), lds, s, p);
     LCV_LAUNCH_CHECK("attn_bwd_dkv");
     if (qsplit > 1) {

@@ -495,9 +495,12 @@ extern "C" int lcv_fm_noise(const void* x0, const void* eps, const float* sigma,
   return LCV_OK;
 }
 
+// Training loss.  Deterministic: every workgroup leaves ONE partial sum (wave sums added in wave order), a second one-workgroup
+// launch adds the LCV_FM_MSE_BLOCKS partials in a fixed tree - no atomics, so two runs of the same step give the same float
+// (the early stopper's strict `<` and the loss logs are reproducible).
 __global__ __launch_bounds__(256) void fm_mse_kernel(const float* __restrict__ pred,
                                                      const bf16_t* __restrict__ eps,
-                                                     const bf16_t* __restrict__ x0, float* __restrict__ loss,
+                                                     const bf16_t* __restrict__ x0, float* __restrict__ parts,
                                                      float* __restrict__ dpred, int64_t BC, int T, int Tc,
                                                      int64_t HW, float inv_n) {
   const int Tt = T - Tc;
@@ -519,27 +522,46 @@ __global__ __launch_bounds__(256) void fm_mse_kernel(const float* __restrict__ p
     }
     if (dpred) dpred[i] = g;
   }
+  __shared__ float red[4];
   acc = wave_sum(acc);
-  if ((threadIdx.x & 63) == 0) atomicAdd(loss, acc * inv_n);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) parts[blockIdx.x] = ((red[0] + red[1]) + (red[2] + red[3])) * inv_n;
 }
 
-extern "C" int lcv_fm_mse(const float* pred, const void* eps, const void* x0, float* loss_out, float* dpred,
+__global__ __launch_bounds__(LCV_FM_MSE_BLOCKS) void fm_mse_sum_kernel(const float* __restrict__ parts, float* __restrict__ loss,
+                                                                       int n) {
+  __shared__ float red[LCV_FM_MSE_BLOCKS];
+  red[threadIdx.x] = (int)threadIdx.x < n ? parts[threadIdx.x] : 0.f;
+  __syncthreads();
+  for (int s = LCV_FM_MSE_BLOCKS / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[0] = red[0];
+}
+
+extern "C" int lcv_fm_mse(const float* pred, const void* eps, const void* x0, float* loss_out, float* dpred, float* ws,
                           int64_t B, int64_t C, int64_t T, int64_t Tc, int64_t HW, void* stream) {
-  LCV_CHECK_ARG(pred && eps && x0 && loss_out, "fm_mse: null pointer");
+  LCV_CHECK_ARG(pred && eps && x0 && loss_out && ws, "fm_mse: null pointer");
   LCV_CHECK_ARG(T > Tc && Tc >= 0, "fm_mse: need at least one target frame (T=%ld, Tc=%ld)", (long)T, (long)Tc);
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(loss_out, 0, sizeof(float), s) != hipSuccess) {
-    lcv_set_error("fm_mse: memset failed");
-    return LCV_EDEVICE;
-  }
   const int64_t total = B * C * T * HW;
-  if (total == 0) return LCV_OK;
+  if (total == 0) {
+    if (hipMemsetAsync(loss_out, 0, sizeof(float), s) != hipSuccess) {
+      lcv_set_error("fm_mse: memset failed");
+      return LCV_EDEVICE;
+    }
+    return LCV_OK;
+  }
   const float inv_n = 1.0f / (float)(B * C * (T - Tc) * HW);
   int64_t bx = (total + 255) / 256;
-  if (bx > 1024) bx = 1024;
+  if (bx > LCV_FM_MSE_BLOCKS) bx = LCV_FM_MSE_BLOCKS;
   hipLaunchKernelGGL(fm_mse_kernel, dim3((unsigned)bx), dim3(256), 0, s, pred, (const bf16_t*)eps,
-                     (const bf16_t*)x0, loss_out, dpred, B * C, (int)T, (int)Tc, HW, inv_n);
+                     (const bf16_t*)x0, ws, dpred, B * C, (int)T, (int)Tc, HW, inv_n);
   LCV_LAUNCH_CHECK("fm_mse");
+  hipLaunchKernelGGL(fm_mse_sum_kernel, dim3(1), dim3(LCV_FM_MSE_BLOCKS), 0, s, ws, loss_out, (int)bx);
+  LCV_LAUNCH_CHECK("fm_mse (sum)");
   return LCV_OK;
 }
 

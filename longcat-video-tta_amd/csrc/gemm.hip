@@ -738,20 +738,27 @@ __global__ __launch_bounds__(512) void gemm8p_nt_kernel(const GemmParams p) {
     swz[t] = (unsigned)(((lane & 7) ^ ((srow >> 1) & 7)) * 16);
   }
   int64_t m0 = 0, n0 = 0;
+  // byte offsets of this tile's first row in each operand (wave-uniform, 64-bit, SGPRs): the per-lane part of a source address is
+  // then (row inside the tile) * row-bytes + swizzle <= 255 * 2 * ld + 112, which fits 32 bits for ANY M (the literal 49x90x160
+  // latent config runs M = 352 800 rows of 22 016 bytes through w2: 7.8e9 bytes from the operand base)
+  int64_t a_tile = 0, a2_tile = 0, w_tile = 0, w2_tile = 0;
   auto setup_tile = [&](int vid) {
     int tm, tn;
     gemm_tile_coords(p, vid, tm, tn);
     m0 = (int64_t)tm * 256;
     n0 = (int64_t)tn * 256;
+    if constexpr (!CONV) { a_tile = m0 * p.lda * 2; a2_tile = m0 * p.lda2 * 2; }
+    w_tile = n0 * p.ldw * 2; w2_tile = n0 * p.ldw2 * 2;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int srow = 8 * (2 * wave + t) + (lane >> 3);
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         int64_t g = m0 + (srow >> 6) * 128 + h * 64 + (srow & 63);
-        arow[h][t] = (int)(g > p.M - 1 ? p.M - 1 : g);
+        g = g > p.M - 1 ? p.M - 1 : g;
+        arow[h][t] = CONV ? (int)g : (int)(g - m0);        // CONV: replaced below by the pixel index of tap (0, 0, 0)
         if constexpr (CONV) {
-          int64_t r2 = arow[h][t];
+          int64_t r2 = g;
           const int wo = (int)(r2 % p.cv_W); r2 /= p.cv_W;
           const int ho = (int)(r2 % p.cv_H); r2 /= p.cv_H;
           const int to = (int)(r2 % p.cv_T);
@@ -772,7 +779,7 @@ __global__ __launch_bounds__(512) void gemm8p_nt_kernel(const GemmParams p) {
           arow[h][t] = ((bb * p.cv_Tin + t0) * p.cv_Hin + hq) * p.cv_Win + wq;
         }
         g = n0 + (srow >> 5) * 64 + h * 32 + (srow & 31);
-        wrow[h][t] = (int)(g > p.N - 1 ? p.N - 1 : g);
+        wrow[h][t] = (int)((g > p.N - 1 ? p.N - 1 : g) - n0);
       }
     }
   };
@@ -782,7 +789,7 @@ __global__ __launch_bounds__(512) void gemm8p_nt_kernel(const GemmParams p) {
     constexpr int mq = decltype(mq_c)::value;
     if constexpr (SPLIT) kts += k_off;
     const bool lora = kts >= p.nk1;  // the rank-r pair (a2, w2) supplies the last nk2 K tiles
-    const char* base = lora ? (const char*)p.a2 + (int64_t)(kts - p.nk1) * 128 : (const char*)p.a + (int64_t)kts * 128;
+    const char* base = lora ? (const char*)p.a2 + a2_tile + (int64_t)(kts - p.nk1) * 128 : (const char*)p.a + a_tile + (int64_t)kts * 128;
     const unsigned ldb = (unsigned)(lora ? p.lda2 : p.lda) * 2u;
     unsigned char* dst = smem + buf * BUF_BYTES + mq * SLOT_BYTES + wave * 2048;
     if constexpr (CONV) {
@@ -819,7 +826,7 @@ __global__ __launch_bounds__(512) void gemm8p_nt_kernel(const GemmParams p) {
     constexpr int nq = decltype(nq_c)::value;
     if constexpr (SPLIT) kts += k_off;
     const bool lora = kts >= p.nk1;
-    const char* base = lora ? (const char*)p.w2 + (int64_t)(kts - p.nk1) * 128 : (const char*)p.w + (int64_t)kts * 128;
+    const char* base = lora ? (const char*)p.w2 + w2_tile + (int64_t)(kts - p.nk1) * 128 : (const char*)p.w + w_tile + (int64_t)kts * 128;
     const unsigned ldb = (unsigned)(lora ? p.ldw2 : p.ldw) * 2u;
     unsigned char* dst = smem + buf * BUF_BYTES + (2 + nq) * SLOT_BYTES + wave * 2048;
 #pragma unroll
@@ -1233,13 +1240,17 @@ static int dispatch_tile(GemmParams& p, hipStream_t s) {
   // 8-phase ping-pong schedule on the same tile; its LDS-DMA sources are 32-bit byte offsets from the operand base
   const bool ok8 = p.nk1 >= 2 && (uint64_t)p.M * p.lda * 2 < (1ull << 32) && (uint64_t)p.N * p.ldw * 2 < (1ull << 32) &&
                    (p.nk2 == 0 || ((uint64_t)p.M * p.lda2 * 2 < (1ull << 32) && (uint64_t)p.N * p.ldw2 * 2 < (1ull << 32)));
-  if (mode == 6 && ok8) mode = 9;  // persistent workgroups (identical to 8 when there are no more tiles than CUs)
+  // round 3: the default 8-phase kernel addresses rows RELATIVE to its tile (64-bit tile base in SGPRs), so only a 256-row
+  // panel has to fit 32 bits: any M (M = 352 800 x K = 11 008 at the literal 49x90x160 config used to fall back to gemm16)
+  const bool ok8t = p.nk1 >= 2 && (uint64_t)256 * p.lda * 2 < (1ull << 31) && (uint64_t)256 * p.ldw * 2 < (1ull << 31) &&
+                    (p.nk2 == 0 || ((uint64_t)256 * p.lda2 * 2 < (1ull << 31) && (uint64_t)256 * p.ldw2 * 2 < (1ull << 31)));
+  if (mode == 6 && ok8t) mode = 9;  // persistent workgroups (identical to 8 when there are no more tiles than CUs)
   if (force) mode = force[0] - '0';
   if (mode == 3 && ok8) return launch_gemm4p<EPI>(p, s);
   if (mode == 4 && ok8) return launch_gemm4w<EPI, 4>(p, s);
   if (mode == 5 && ok8) return launch_gemm4w<EPI, 8>(p, s);
-  if (mode == 8 && ok8) return launch_gemm8p<EPI, false>(p, s);
-  if (mode == 9 && ok8) return launch_gemm8p<EPI, true>(p, s);
+  if (mode == 8 && ok8t) return launch_gemm8p<EPI, false>(p, s);
+  if (mode == 9 && ok8t) return launch_gemm8p<EPI, true>(p, s);
   if (mode == 6 || mode == 8 || mode == 9) return launch_gemm16<256, 256, 2, 4, EPI, false>(p, s);
   if (mode == 7) return launch_gemm16<128, 128, 2, 2, EPI, false>(p, s);
   if (mode == 2) return launch_gemm<256, 256, 2, 4, EPI, false>(p, s);

@@ -469,6 +469,14 @@ def _sp_attention_overlapped(q, k_loc, v_loc, sp):
         parts.append(ops.attention(q, k_full[:, :lo], v_full[:, :lo], ops.LN2, need_lse=True))
     if hi < k_full.shape[1]:
         parts.append(ops.attention(q, k_full[:, hi:], v_full[:, hi:], ops.LN2, need_lse=True))
+    return merge_attention_parts(parts)
+
+
+def merge_attention_parts(parts):
+    """[(o_i bf16 [B, N, H, D], lse_i fp32 [B, H, N])] of ONE query set over disjoint key ranges -> the attention over their
+    union: o = sum_i o_i * exp(lse_i - lse), lse = logsumexp_i(lse_i).  `lse_i` is what `ops.attention(..., need_lse=True)`
+    returns: the NATURAL logarithm of the row's sum of exp(scale * q.k) (the kernels keep m_run * scale + ln(l), also when
+    they run in log2 units internally with scale = ln 2) - pinned by tests/test_gpu_kernels.py on one GPU."""
     if len(parts) == 1:
         return parts[0][0]
     lses = torch.stack([l for _, l in parts], 0)                               # [P, B, H, N] natural-log units

@@ -41,7 +41,7 @@ _SIGNATURES = {
     "lcv_cfg_euler_step": [P, P, P, P, I64, I64, F32, F32, I, I, P],
     "lcv_euler_step": [P, P, I64, F32, I, P],
     "lcv_fm_noise": [P, P, P, P, I64, I64, P],
-    "lcv_fm_mse": [P, P, P, P, P, I64, I64, I64, I64, I64, P],
+    "lcv_fm_mse": [P, P, P, P, P, P, I64, I64, I64, I64, I64, P],
     "lcv_fm_mse_samples": [P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, P],
     "lcv_grad_norm_clip": [P, I64, I64, I, F32, P, P, P],
     "lcv_adamw_step": [P, I64, I64, I, P, F64, F64, F64, F64, F64, I64, P],
@@ -107,6 +107,8 @@ def load():
     lib.lcv_conv3d_last_kernel.argtypes = []
     lib.lcv_tn_skinny_ws_bytes.restype = c_int64     # a size, not a status
     lib.lcv_tn_skinny_ws_bytes.argtypes = [I64, I64, I64]
+    lib.lcv_attn_bwd_ws_floats.restype = c_int64     # likewise
+    lib.lcv_attn_bwd_ws_floats.argtypes = [I64, I64, I64, I64]
     for name, args in _SIGNATURES.items():
         fn = getattr(lib, name, None)
         if fn is None:

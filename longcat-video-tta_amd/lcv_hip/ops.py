@@ -306,8 +306,9 @@ def fm_mse(pred: torch.Tensor, eps: torch.Tensor, x0: torch.Tensor, Tc: int, nee
                             f"with T_cond={Tc}")
     loss = torch.empty((1,), dtype=F32, device=pred.device)
     dpred = torch.empty_like(pred) if need_grad else None
+    ws = torch.empty((1024,), dtype=F32, device=pred.device)        # lcv_hip.h: LCV_FM_MSE_BLOCKS per-workgroup partial sums
     call("lcv_fm_mse", _ptr(pred.contiguous()), _ptr(eps.contiguous()), _ptr(x0.contiguous()), _ptr(loss),
-         _ptr(dpred), B, C, T, Tc, H * W, _stream())
+         _ptr(dpred), _ptr(ws), B, C, T, Tc, H * W, _stream())
     return loss[0], dpred
 
 
@@ -410,8 +411,7 @@ def attention_bwd(q, k, v, o, do, lse, dq, dk, dv, scale, accumulate_kv=False):
         do = do.contiguous()
         if do.stride() != o.stride():
             raise _lib.LcvError("attention_bwd: dO must share O's strides")
-    delta = torch.empty((B * H * (Nq + 2 * ((Nq + 31) // 32 * 32) + (Nk * 256 if Nk <= 128 else 0)),), dtype=F32,
-                        device=q.device)   # lcv_hip.h: delta_ws
+    delta = torch.empty((max(int(_lib.load().lcv_attn_bwd_ws_floats(B, H, Nq, Nk)), 1),), dtype=F32, device=q.device)   # lcv_hip.h: delta_ws
     if PROFILE_BWD is not None:   # bench.py: HIP events on the launch stream around the whole backward of this region
         ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
         ev0.record()

@@ -57,6 +57,8 @@ def _pack_plan(mask: torch.Tensor):
 
 
 class LongCatVideoTransformer3DModel(nn.Module):
+    supports_cond_kv_cache = True      # forward(..., return_kv= / skip_crs_attn= / kv_cache_dict=): the conditioning-frame KV cache
+
     def __init__(self, device=None, dtype=torch.bfloat16, **cfg):
         super().__init__()
         c = dict(_DEFAULT_CONFIG)

@@ -51,18 +51,96 @@ def host_group():
     return _HOST_GROUP
 
 
-def gather_results(local_rows: List[Dict[str, Any]], group=None) -> Optional[List[Dict[str, Any]]]:
-    """All ranks call; rank 0 gets the merged list (one `gather_object` over the HOST group: the only collective of the DP
-    path, and never on the device's collective queue)."""
+LAST_MERGE_MISSING: List[int] = []      # ranks whose final rows rank 0 did not get in time (filled by gather_results)
+_JOB_START = {}
+
+
+def _deposit_path(output_dir: str, rank: int) -> str:
+    return os.path.join(output_dir, f"results.rank{rank}.json")
+
+
+def begin_job(output_dir: str, rank: int) -> None:
+    """Call once per rank right after the output directory exists: clears this rank's end-of-job deposit of an earlier run
+    in the same directory (a resumed job) and notes when this job started."""
+    import time
+    _JOB_START[os.path.abspath(output_dir)] = time.time()
+    try:
+        os.remove(_deposit_path(output_dir, rank))
+    except FileNotFoundError:
+        pass
+
+
+def merge_wait_seconds(per_video_s: float = 0.0, videos_per_rank: int = 1) -> float:
+    """How long rank 0 waits for the other ranks' final rows: the expected time of a whole shard again (ranks start together
+    and do equal shares, so a healthy peer is at most about one video behind), never under 15 minutes; LCV_DP_MERGE_WAIT_S
+    overrides."""
+    env = os.environ.get("LCV_DP_MERGE_WAIT_S")
+    if env:
+        return float(env)
+    return max(900.0, 2.0 * float(per_video_s) * max(int(videos_per_rank), 1))
+
+
+def gather_results(local_rows: List[Dict[str, Any]], group=None, output_dir: Optional[str] = None,
+                   wait_s: Optional[float] = None, poll_s: float = 2.0) -> Optional[List[Dict[str, Any]]]:
+    """All ranks call; rank 0 gets the merged list, the others None.
+
+    With `output_dir` (what the runners pass) the merge is a FILE rendezvous with a bounded wait, no collective at all: every
+    rank deposits its final rows as `results.rank{r}.json` (atomic rename) and leaves; rank 0 polls for the W deposits for at
+    most `wait_s` seconds.  A peer that wedged (a hung GPU does not exit, so no socket closes and a host-side gather would
+    sit there for its whole timeout) costs that bounded wait: rank 0 then takes the peer's rows from its per-video
+    `checkpoint.rank{r}.json` - written after every video - records the rank in `LAST_MERGE_MISSING`, still returns the merged
+    rows so that `summary.json` gets written, and the runner exits non-zero (`exit_code_after_merge`).
+    Without `output_dir`: one `gather_object` over the host (gloo) group, as before."""
     import torch.distributed as dist
+    del LAST_MERGE_MISSING[:]
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return merge_results([local_rows])
-    if group is None:
-        group = host_group()
-    world = dist.get_world_size(group)
-    out = [None] * world if dist.get_rank(group) == 0 else None
-    dist.gather_object(local_rows, out, dst=0, group=group)
-    return merge_results(out) if out is not None else None
+    if output_dir is None:
+        if group is None:
+            group = host_group()
+        world = dist.get_world_size(group)
+        out = [None] * world if dist.get_rank(group) == 0 else None
+        dist.gather_object(local_rows, out, dst=0, group=group)
+        return merge_results(out) if out is not None else None
+    import time
+    rank, world = dist.get_rank(), dist.get_world_size()
+    tmp = _deposit_path(output_dir, rank) + ".tmp"
+    with open(tmp, "w") as f:
+        json.dump({"finished": True, "rank": rank, "results": local_rows}, f, default=str)
+    os.replace(tmp, _deposit_path(output_dir, rank))
+    if rank != 0:
+        return None
+    started = _JOB_START.get(os.path.abspath(output_dir), 0.0)
+    deadline = time.time() + (merge_wait_seconds() if wait_s is None else float(wait_s))
+    per_rank: Dict[int, List[Dict[str, Any]]] = {0: local_rows}
+    while True:
+        for r in range(1, world):
+            p = _deposit_path(output_dir, r)
+            if r in per_rank or not os.path.exists(p) or os.path.getmtime(p) < started - 60.0:
+                continue                                 # not there yet, or a leftover of an earlier job in this directory
+            try:
+                with open(p) as f:
+                    per_rank[r] = json.load(f)["results"]
+            except (OSError, ValueError, KeyError):
+                pass                                     # caught mid-replace on a network file system: next poll
+        if len(per_rank) == world or time.time() >= deadline:
+            break
+        time.sleep(poll_s)
+    for r in range(1, world):
+        if r in per_rank:
+            continue
+        LAST_MERGE_MISSING.append(r)
+        ck = load_checkpoint(output_dir, r)
+        per_rank[r] = ck["results"] if ck else []
+        print(f"  WARNING: rank {r} did not deliver its final results within the wait; merged its per-video checkpoint "
+              f"({len(per_rank[r])} rows) instead")
+    return merge_results([per_rank[r] for r in sorted(per_rank)])
+
+
+def exit_code_after_merge() -> int:
+    """0 after a complete merge; 3 when rank 0 had to fall back to a peer's checkpoint file (the summary exists, the job did
+    not finish cleanly)."""
+    return 3 if LAST_MERGE_MISSING else 0
 
 
 def write_checkpoint(output_dir: str, next_idx: int, results: List[Dict[str, Any]], rank: Optional[int] = None):

@@ -57,6 +57,7 @@ def main(argv=None):
     torch.manual_seed(args.seed)
     np.random.seed(args.seed)
     os.makedirs(args.output_dir, exist_ok=True)
+    dp.begin_job(args.output_dir, rank)
     videos_dir = os.path.join(args.output_dir, "videos"); os.makedirs(videos_dir, exist_ok=True)
     prior = None if args.restart else dp.load_checkpoint(args.output_dir, rank if world > 1 else None)
     all_results = prior["results"] if prior else []
@@ -145,7 +146,11 @@ def main(argv=None):
                 raise
         dp.write_checkpoint(args.output_dir, idx + world, all_results, rank=rank if world > 1 else None)
 
-    merged = dp.gather_results(all_results) if world > 1 else dp.merge_results([all_results])
+    # end-of-job merge: file rendezvous with a bounded wait (a wedged peer must not park this rank for a day)
+    took = [r.get("total_time") or r.get("train_time") or 0.0 for r in all_results if r.get("success")]
+    wait_s = dp.merge_wait_seconds(max(took) if took else 0.0, len(all_results))
+    merged = (dp.gather_results(all_results, output_dir=args.output_dir, wait_s=wait_s) if world > 1
+              else dp.merge_results([all_results]))
     if rank == 0:
         ok = [r for r in merged if r.get("success", False)]
         mean = lambda k: float(np.mean([r.get(k, 0.0) or 0.0 for r in ok])) if ok else 0
@@ -169,6 +174,8 @@ def main(argv=None):
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
+        if rank == 0 and dp.exit_code_after_merge():
+            sys.exit(dp.exit_code_after_merge())      # summary.json is written, but a peer never delivered its final rows
 
 
 if __name__ == "__main__":

@@ -40,12 +40,19 @@ class _HookedWrapper(nn.Module):
             h.remove()
         self._hooks = []
 
+    # the early stopper may score its anchors through the conditioning-frame KV cache (tta/early_stopping.py::_AnchorSet): the
+    # hooks below act on the cache pass and on the cached pass exactly as they do on the pinned sequence, which is also how the
+    # continuation runs them (`apply_to_dit()` around `pipe.generate_vc`, whose first call is the cache pass)
+    supports_cond_kv_cache = True
+    _CACHE_KW = ("return_kv", "skip_crs_attn", "kv_cache_dict")
+
     def forward(self, hidden_states, timestep, encoder_hidden_states, encoder_attention_mask=None,
                 num_cond_latents=0, **kwargs):
+        cache_kw = {k: kwargs[k] for k in self._CACHE_KW if k in kwargs}
         self.apply_to_dit()
         try:
             return self.dit(hidden_states=hidden_states, timestep=timestep, encoder_hidden_states=encoder_hidden_states,
-                            encoder_attention_mask=encoder_attention_mask, num_cond_latents=num_cond_latents)
+                            encoder_attention_mask=encoder_attention_mask, num_cond_latents=num_cond_latents, **cache_kw)
         finally:
             self.remove_from_dit()
 
@@ -141,9 +148,12 @@ class DeltaCWrapper(_HookedWrapper):
 
     def forward(self, hidden_states, timestep, encoder_hidden_states, encoder_attention_mask=None,
                 num_cond_latents=0, **kwargs):
+        cache_kw = {k: kwargs[k] for k in self._CACHE_KW if k in kwargs}
         with torch.no_grad():
             pred = self.dit(hidden_states=hidden_states, timestep=timestep, encoder_hidden_states=encoder_hidden_states,
-                            encoder_attention_mask=encoder_attention_mask, num_cond_latents=num_cond_latents)
+                            encoder_attention_mask=encoder_attention_mask, num_cond_latents=num_cond_latents, **cache_kw)
+        if isinstance(pred, tuple):          # the cache pass: (prediction, per-block K / V)
+            return (pred[0] + self.delta_out.view(1, -1, 1, 1, 1).to(pred[0].dtype),) + pred[1:]
         return pred + self.delta_out.view(1, -1, 1, 1, 1).to(pred.dtype)
 
 
@@ -329,9 +339,12 @@ class NormTuneForward(nn.Module):
             self._delta_hook.remove()
             self._delta_hook = None
 
+    supports_cond_kv_cache = True
+
     def forward(self, hidden_states, timestep, encoder_hidden_states, encoder_attention_mask=None, num_cond_latents=0, **kw):
+        cache_kw = {k: kw[k] for k in _HookedWrapper._CACHE_KW if k in kw}
         return self.dit(hidden_states=hidden_states, timestep=timestep, encoder_hidden_states=encoder_hidden_states,
-                        encoder_attention_mask=encoder_attention_mask, num_cond_latents=num_cond_latents)
+                        encoder_attention_mask=encoder_attention_mask, num_cond_latents=num_cond_latents, **cache_kw)
 
 
 def optimize_norm_params(wrapper: NormTuneForward, cond_latents, train_latents, prompt_embeds, prompt_mask, num_steps: int = 20,

@@ -91,38 +91,70 @@ class ParamSnapshot:
 
 class _AnchorSet:
     """The fixed (sigma, noise) pairs of one video as a resident batch, ordered sigma-major like the reference's double
-    loop so the host-side mean adds the per-sample losses in the same order."""
+    loop so the host-side mean adds the per-sample losses in the same order.
+
+    Every sample is `[cond | noisy val]`, and the conditioning tokens are the SAME in all of them: clean latents at
+    t = 0 that attend only each other and receive no text update - their K / V do not depend on the sample.  A model
+    that offers the conditioning-frame KV cache (`supports_cond_kv_cache`: the drop-in DiT and the wrappers of
+    `tta/delta.py`; the generation path's `pipe.cache_clean_latents` uses the same two calls) is therefore scored as
+    ONE pass over the conditioning frames (B = 1, cross-attention skipped, K / V kept per block) + ONE pass over the
+    six noisy anchor clips against those cached keys: at the K3-TTA split 14 400 + 6 x 3 600 token rows per check
+    instead of 6 x 18 000.  The cache is rebuilt at every check (the adapters being trained sit inside qkv).  Anything
+    else - a caller-supplied `forward_fn`, a foreign model - gets the full `[cond | noisy]` batch."""
 
     def __init__(self, model, cond_latents, val_latents, sigmas, noises, device, dtype):
-        patch_t = FM._get_model_config(model).patch_size[0]
+        if val_latents.shape[0] != 1:
+            raise ValueError("the anchor clip is one video: expected a leading dimension of 1")
+        cfg = FM._get_model_config(model)
+        patch_t = cfg.patch_size[0]
         hs, ts, eps = [], [], []
         for s in sigmas:
             sig = torch.tensor([s], device=device, dtype=torch.float32)
             for n in noises:
                 h, t, self.n_cond = FM._build_inputs(cond_latents, val_latents, sig, n, patch_t, 1000, dtype, device)
                 hs.append(h); ts.append(t); eps.append(n.to(torch.bfloat16))
-        self.hidden = torch.cat(hs, 0)
+        self.hidden = torch.cat(hs, 0)                                 # [S, C, Tc + Tv, h, w]: the full-sequence form
         self.timestep = torch.cat(ts, 0)
         self.eps = torch.cat(eps, 0)
         self.x0 = val_latents.to(torch.bfloat16)[:1].contiguous()     # shared by every sample (stride 0 in the kernel)
         self.t_cond = cond_latents.shape[2]
         self.size = self.hidden.shape[0]
-        if val_latents.shape[0] != 1:
-            raise ValueError("the anchor clip is one video: expected a leading dimension of 1")
+        # the cached form's inputs are views of the same tensors: conditioning frames once, noisy frames per sample
+        self.cond = self.hidden[:1, :, :self.t_cond]
+        self.noisy = self.hidden[:, :, self.t_cond:]
+        self.ts_cond = self.timestep[:1, :self.n_cond]
+        self.ts_noisy = self.timestep[:, self.n_cond:]
+        self.text_dim = int(getattr(cfg, "caption_channels", 0) or 0)
+
+    def _cached_ok(self, model, prompt_embeds, forward_fn) -> bool:
+        return (forward_fn is None and self.n_cond > 0 and prompt_embeds is not None
+                and bool(getattr(model, "supports_cond_kv_cache", False)))
 
     @torch.no_grad()
-    def sample_losses(self, model, prompt_embeds, prompt_mask, forward_fn) -> List[float]:
+    def predictions(self, model, prompt_embeds, prompt_mask, forward_fn):
+        """(prediction fp32, number of leading conditioning frames it still carries)."""
         B = self.size
         if forward_fn is not None:
             # a caller-supplied forward owns its text tensors (batch 1): feed it the resident samples one at a time
-            pred = torch.cat([forward_fn(self.hidden[i:i + 1], self.timestep[i:i + 1], self.n_cond).float()
-                              for i in range(B)], 0)
-        else:
-            emb = prompt_embeds.expand(B, *prompt_embeds.shape[1:])
-            mask = None if prompt_mask is None else prompt_mask.expand(B, *prompt_mask.shape[1:])
-            pred = model(hidden_states=self.hidden, timestep=self.timestep, encoder_hidden_states=emb,
-                         encoder_attention_mask=mask, num_cond_latents=self.n_cond)
-        per_sample = ops.fm_mse_samples(pred.to(torch.float32).contiguous(), self.eps, self.x0, self.t_cond)
+            return torch.cat([forward_fn(self.hidden[i:i + 1], self.timestep[i:i + 1], self.n_cond).float()
+                              for i in range(B)], 0), self.t_cond
+        emb = prompt_embeds.expand(B, *prompt_embeds.shape[1:])
+        mask = None if prompt_mask is None else prompt_mask.expand(B, *prompt_mask.shape[1:])
+        if self._cached_ok(model, prompt_embeds, forward_fn):
+            no_text = torch.zeros((1, 1, 64, prompt_embeds.shape[-1]), device=self.hidden.device, dtype=prompt_embeds.dtype)
+            _, kv = model(hidden_states=self.cond.contiguous(), timestep=self.ts_cond.contiguous(), encoder_hidden_states=no_text,
+                          return_kv=True, skip_crs_attn=True)
+            pred = model(hidden_states=self.noisy.contiguous(), timestep=self.ts_noisy.contiguous(), encoder_hidden_states=emb,
+                         encoder_attention_mask=mask, num_cond_latents=self.n_cond, kv_cache_dict=kv)
+            return pred, 0
+        pred = model(hidden_states=self.hidden, timestep=self.timestep, encoder_hidden_states=emb,
+                     encoder_attention_mask=mask, num_cond_latents=self.n_cond)
+        return pred, self.t_cond
+
+    @torch.no_grad()
+    def sample_losses(self, model, prompt_embeds, prompt_mask, forward_fn) -> List[float]:
+        pred, lead = self.predictions(model, prompt_embeds, prompt_mask, forward_fn)
+        per_sample = ops.fm_mse_samples(pred.to(torch.float32).contiguous(), self.eps, self.x0, lead)
         return per_sample.tolist()                                     # the one host sync of a check
 
 
@@ -151,6 +183,13 @@ class AnchoredEarlyStopper:
 
     def setup(self, model, cond_latents, val_latents, prompt_embeds, prompt_mask, device="cuda", dtype=torch.bfloat16,
               forward_fn=None, video_id="", save_fn=None):
+        """`val_latents` must be bf16 - what `load_entry` / `encode_video(...).to(dtype)` hand over, and the dtype in which
+        the reference then evaluates `(noise - target)` (common.py:552 on bf16 latents).  The HIP loss kernels read the
+        noise and the target as raw bf16; an fp32 clip would be scored against a bf16-rounded target where the reference
+        keeps fp32, so it is refused here instead of being rounded silently."""
+        if val_latents.dtype != torch.bfloat16:
+            raise TypeError(f"AnchoredEarlyStopper.setup: val_latents must be bfloat16 (got {val_latents.dtype}); cast the "
+                            "held-out latents with .to(torch.bfloat16) as the runners' load_entry does")
         self._clear()
         self.model, self.forward_fn = model, forward_fn
         self.prompt_embeds, self.prompt_mask = prompt_embeds, prompt_mask

@@ -5,6 +5,7 @@ parallelism over videos, the KV-cached CFG continuation, and the reference's `ch
 `save_checkpoint` common.py:2055-2059).  The LoRA runner has its own main (it also writes `config.json`)."""
 import json
 import os
+import sys
 import time
 from pathlib import Path
 from typing import Callable, Dict
@@ -266,6 +267,7 @@ def run_delta_method(args, method: str, make_wrapper: Callable, optimize_fn: Cal
     torch.manual_seed(args.seed)
     np.random.seed(args.seed)
     os.makedirs(args.output_dir, exist_ok=True)
+    dp.begin_job(args.output_dir, rank)
     videos_dir = os.path.join(args.output_dir, "videos"); os.makedirs(videos_dir, exist_ok=True)
     prior = dp.load_checkpoint(args.output_dir, rank if world > 1 else None)
     all_results = prior["results"] if prior else []
@@ -290,12 +292,14 @@ def run_delta_method(args, method: str, make_wrapper: Callable, optimize_fn: Cal
             choose_gradient_checkpointing(dit, n_tok)
             wrapper = make_wrapper(dit).to(device)
             pe, pm = blob["prompt_embeds"], blob["prompt_mask"]
+            # variants first (as in the LoRA / full runners): a synthetic entry's cond / train latents are REPLACED by the encode
+            # of its own pixels, and the stopper's resident anchor batch must be built from the clip the loop trains on
+            cond, train, variants = train_latents_variants_for(args, pipe, blob, e, cond, train, device)
             es = early_stopper if (early_stopper is not None and val is not None) else None
             if es is not None:
                 # the wrapper is called directly, so the stopper scores its whole anchor set in one batched forward
                 es.setup(model=wrapper, cond_latents=cond, val_latents=val, prompt_embeds=pe, prompt_mask=pm, device=device,
                          dtype=torch.bfloat16, video_id=e["name"])
-            cond, train, variants = train_latents_variants_for(args, pipe, blob, e, cond, train, device)
             t0 = time.time()
             opt = optimize_fn(wrapper, cond, train, pe, pm, device, es, variants)
             torch.cuda.synchronize()
@@ -342,7 +346,11 @@ def run_delta_method(args, method: str, make_wrapper: Callable, optimize_fn: Cal
                 cleanup(wrapper)   # e.g. norm tuning: put the job's original weights back before the next video
         dp.write_checkpoint(args.output_dir, idx + world, all_results, rank=rank if world > 1 else None)
 
-    merged = dp.gather_results(all_results) if world > 1 else dp.merge_results([all_results])
+    # end-of-job merge: file rendezvous with a bounded wait (a wedged peer must not park this rank for a day)
+    took = [r.get("total_time") or r.get("train_time") or 0.0 for r in all_results if r.get("success")]
+    wait_s = dp.merge_wait_seconds(max(took) if took else 0.0, len(all_results))
+    merged = (dp.gather_results(all_results, output_dir=args.output_dir, wait_s=wait_s) if world > 1
+              else dp.merge_results([all_results]))
     if rank == 0:
         ok = [r for r in merged if r.get("success", False)]
         mean = lambda k: float(np.mean([r.get(k, 0.0) or 0.0 for r in ok])) if ok else 0
@@ -365,3 +373,5 @@ def run_delta_method(args, method: str, make_wrapper: Callable, optimize_fn: Cal
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
+        if rank == 0 and dp.exit_code_after_merge():
+            sys.exit(dp.exit_code_after_merge())      # summary.json is written, but a peer never delivered its final rows

@@ -30,7 +30,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     so.lcv_version.restype = ctypes.c_int
     assert so.lcv_version() >= 1          # host-only call
     table = set(lib._SIGNATURES) | {"lcv_version", "lcv_last_error", "lcv_attn_fwd_last_kernel", "lcv_tn_skinny_ws_bytes",
-                                       "lcv_conv3d_last_kernel"}
+                                       "lcv_conv3d_last_kernel", "lcv_attn_bwd_ws_floats"}
     assert set(names) == table, (set(names) ^ table)
 
 

@@ -33,6 +33,32 @@ def _worker(rank, world, port, tmp):
             dp.write_checkpoint(tmp, dp.contiguous_next_idx(merged), merged)
         else:
             assert merged is None
+        # ---- the runners' form: a file rendezvous with a bounded wait, no collective (round 3)
+        dp.begin_job(tmp, rank)
+        dist.barrier()
+        merged = dp.gather_results(rows, output_dir=tmp, wait_s=60.0, poll_s=0.05)
+        if rank == 0:
+            assert [r["idx"] for r in merged] == list(range(7)) and dp.exit_code_after_merge() == 0
+        else:
+            assert merged is None
+        dist.barrier()
+        # a wedged peer: rank 1 never delivers (its GPU hung; it did not exit).  Rank 0 waits the bounded time, takes rank 1's
+        # rows from the per-video checkpoint it wrote after its LAST FINISHED video, still merges, and reports a non-zero code
+        dp.begin_job(tmp, rank)
+        dist.barrier()
+        if rank == 1:
+            dp.write_checkpoint(tmp, mine[0] + world, rows[:1], rank=rank)        # one video done, then it hangs
+        dist.barrier()
+        if rank == 0:
+            import time
+            t0 = time.time()
+            merged = dp.gather_results(rows, output_dir=tmp, wait_s=0.5, poll_s=0.05)
+            assert 0.4 < time.time() - t0 < 10.0
+            assert dp.LAST_MERGE_MISSING == [1] and dp.exit_code_after_merge() == 3
+            assert [r["idx"] for r in merged] == sorted([r["idx"] for r in rows] + [mine_of_1[0] for mine_of_1 in [dp.shard_indices(7, 1, world)]])
+        dist.barrier()
+        if rank == 1:
+            dp.write_checkpoint(tmp, (mine[-1] + world) if mine else rank, rows, rank=rank)   # restore for the asserts after the spawn
         # ---- SP: frame-axis shards (uneven: 5 frames over 2 ranks -> 3 + 2), all-gather of K/V rows
         T, S, H, D = 5, 6, 2, 8
         counts = sp.frame_shards(T, world)

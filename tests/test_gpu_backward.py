@@ -44,6 +44,10 @@ def test_attention_backward(B, H, Nq, Nk):
     assert rel_l2(dq.permute(0, 2, 1, 3), qf.grad) < 1e-2
     assert rel_l2(dk.permute(0, 2, 1, 3), kf.grad) < 1e-2
     assert rel_l2(dv.permute(0, 2, 1, 3), vf.grad) < 1e-2
+    # no atomics on any path (the split query sweep of the short-key form keeps a slice per split): a second call gives the same bits
+    dq_b = torch.empty_like(qd); dk_b = torch.empty_like(kd); dv_b = torch.empty_like(vd)
+    ops.attention_bwd(qd, kd, vd, o, dod, lse, dq_b, dk_b, dv_b, scale)
+    assert torch.equal(dq, dq_b) and torch.equal(dk, dk_b) and torch.equal(dv, dv_b)
     # accumulate_kv adds into existing dk/dv
     dk2 = dk.clone(); dv2 = dv.clone()
     ops.attention_bwd(qd, kd, vd, o, dod, lse, dq, dk2, dv2, scale, accumulate_kv=True)

@@ -13,9 +13,15 @@ baseline_experiment/scripts/run_baseline.py:409-420) against `oracle/pipeline_or
 
 At K2 / K3 the oracle cannot run on host cores in seconds (1.5 PFLOP of fp32 per CFG step), so the SAME oracle code is
 evaluated with plain PyTorch fp32 ops on the card (`device="cuda"`; `test_oracle_is_device_independent` checks that this
-changes nothing beyond fp32 summation order).  Tolerances are written beside each assert; measured values are printed and
-written to gpurun_out/denoise_parity.json.  bf16 has eps = 7.8e-3, so "1e-3 rel" (north_star) is read as the order of the
-relative-L2 gap, not an element-wise bound."""
+changes nothing beyond fp32 summation order).  bf16 has eps = 7.8e-3, so "1e-3 rel" (north_star) is read as the order of the
+relative-L2 gap, not an element-wise bound.
+
+ONE criterion everywhere (round 3; the round-2 file mixed it with absolute bounds 3-5 x above what was measured):
+  (a) the HIP path is no further from the fp32 oracle than the oracle's own bf16-rounding-point evaluation is:
+      hip_vs_fp32 < 1.5 * oracle_bf16_vs_fp32 + 1e-3;
+  (b) the HIP path stays within 1.5 x of ITS OWN measured distance to the bf16-point oracle (`_MEASURED_R2` below: the values of
+      gpurun_out/denoise_parity.json at the end of round 2) - a regression that doubled an error fails.
+The three numbers per config are printed and written to gpurun_out/denoise_parity.json."""
 import json
 import os
 from pathlib import Path
@@ -29,6 +35,17 @@ pytestmark = pytest.mark.gpu
 BF16 = torch.bfloat16
 DEV = "cuda"
 _REPORT = {}
+# rel-L2 of the HIP path vs the bf16-point oracle as measured at the end of round 2 (MI355X, deterministic kernels)
+_MEASURED_R2 = {
+    "k1_ncond0_kv1": {"latents": 4.87e-3, "update": 4.43e-3},
+    "k1_ncond2_kv1": {"latents": 4.85e-3, "update": 4.40e-3},
+    "k1_ncond2_kv0": {"latents": 5.81e-3, "update": 6.11e-3},
+    "depth_sweep_k1": {2: 4.06e-3, 4: 5.38e-3, 8: 6.35e-3, 16: 7.44e-3, 48: 1.029e-2},
+    "k2_depth48_cfg_step": {"pred": 1.053e-2, "update": 1.293e-2, "latents": 1.118e-3},
+    "k3_depth48_forward": 1.031e-2,
+    "zero_pad_branch": 2.2e-3,
+    "oracle_cuda_vs_cpu_bf16": 3.4e-3,
+}
 
 
 def _record(key, value):
@@ -97,27 +114,34 @@ def test_k1_denoise_matches_cpu_oracle_every_step(dit2, ncond, use_kv, steps):
     pipe = _pipe(dit2)
     lat = torch.randn(1, 16, 5, 32, 32, generator=torch.Generator().manual_seed(42))
     pe, pm, ne, nm = _text()
-    got, ref = [], []
+    got, ref, ref32 = [], [], []
     pipe.denoise(lat.to(DEV), pe.to(DEV), pm.to(DEV), ne.to(DEV), nm.to(DEV), num_cond_latents=ncond,
                  num_inference_steps=steps, guidance_scale=4.0, use_kv_cache=use_kv,
                  step_callback=lambda i, x: got.append(x.detach().float().cpu().clone()))
     PO.denoise(P, cfg, lat, pe, pm, ne, nm, num_cond_latents=ncond, num_inference_steps=steps, guidance_scale=4.0,
                use_kv_cache=use_kv, bf16=True, step_callback=lambda i, x: ref.append(x.clone()))
-    assert len(got) == len(ref) == steps
-    errs = []
+    # the fp32 ground truth (no rounding points), evaluated with fp32 torch ops on the card (== the CPU to 1e-5)
+    PO.denoise(_P(dit2, DEV), cfg, lat.to(DEV), pe.to(DEV), pm.to(DEV), ne.to(DEV), nm.to(DEV), num_cond_latents=ncond,
+               num_inference_steps=steps, guidance_scale=4.0, use_kv_cache=use_kv, bf16=False,
+               step_callback=lambda i, x: ref32.append(x.cpu().clone()))
+    assert len(got) == len(ref) == len(ref32) == steps
+    errs, errs32, own = [], [], []
     for i in range(steps):
-        g_i, r_i = got[i], ref[i]
+        g_i, r_i, f_i = got[i], ref[i], ref32[i]
         if g_i.shape[2] != r_i.shape[2]:          # the KV-cached product loop hands its callback the noise frames only
-            r_i = r_i[:, :, -g_i.shape[2]:]
-        # the update of a step, not the (large, shared) starting noise, carries the information
-        errs.append(rel_l2(g_i, r_i))
-    upd = rel_l2(got[-1] - lat[:, :, -got[-1].shape[2]:], ref[-1][:, :, -got[-1].shape[2]:] - lat[:, :, -got[-1].shape[2]:])
-    print(f"K1 ncond={ncond} kv={use_kv}: latents rel-L2 per step {['%.2e' % e for e in errs]}; accumulated update rel-L2 {upd:.2e}")
-    _record(f"k1_ncond{ncond}_kv{int(use_kv)}", {"latents_rel_l2_per_step": errs, "update_rel_l2": upd})
-    # measured 4.3-4.9e-3 per step (4 steps: |dt| = 1/3 each, so the update is as large as the latents themselves and the
-    # CFG combination multiplies the difference of two bf16 forwards by the guidance scale 4)
-    assert max(errs) < 1e-2, errs
-    assert upd < 1.5e-2, upd
+            r_i, f_i = r_i[:, :, -g_i.shape[2]:], f_i[:, :, -g_i.shape[2]:]
+        errs.append(rel_l2(g_i, r_i)); errs32.append(rel_l2(g_i, f_i)); own.append(rel_l2(r_i, f_i))
+    n = got[-1].shape[2]
+    upd = rel_l2(got[-1] - lat[:, :, -n:], ref[-1][:, :, -n:] - lat[:, :, -n:])   # the update, not the (large, shared) starting noise
+    key = f"k1_ncond{ncond}_kv{int(use_kv)}"
+    print(f"K1 ncond={ncond} kv={use_kv}: per step HIP-vs-oracle(bf16 points) {['%.2e' % e for e in errs]}, HIP-vs-fp32 "
+          f"{['%.2e' % e for e in errs32]}, oracle bf16-vs-fp32 {['%.2e' % e for e in own]}; accumulated update rel-L2 {upd:.2e}")
+    _record(key, {"latents_rel_l2_per_step": errs, "hip_vs_fp32_per_step": errs32, "oracle_bf16_vs_fp32_per_step": own,
+                  "update_rel_l2": upd})
+    m = _MEASURED_R2[key]
+    for i in range(steps):
+        assert errs32[i] < 1.5 * own[i] + 1e-3, (i, errs32, own)                      # (a)
+    assert max(errs) < 1.5 * m["latents"] and upd < 1.5 * m["update"], (errs, upd)    # (b)
 
 
 @pytest.mark.parametrize("ncond,use_kv", [(0, True), (2, True), (2, False)])
@@ -167,7 +191,8 @@ def test_oracle_is_device_independent(dit2):
     # measured 3.4e-3: bf16 rounding points flip on fp32 last-bit differences between the two devices' summation orders —
     # the oracle's OWN sensitivity, and the scale against which the HIP-vs-oracle gaps below (4e-3 at depth 2) are read;
     # the fp32 mode is the tight check
-    assert e < 6e-3
+    _record("oracle_cuda_vs_cpu_bf16", e)
+    assert e < 1.5 * _MEASURED_R2["oracle_cuda_vs_cpu_bf16"]
     a32 = D.dit_forward(_P(dit2, "cpu"), cfg, hs, ts, pe, pm, 1, bf16=False)
     b32 = D.dit_forward(_P(dit2, DEV), cfg, hs.to(DEV), ts.to(DEV), pe.to(DEV), pm.to(DEV), 1, bf16=False)
     assert rel_l2(b32, a32) < 1e-5
@@ -203,8 +228,8 @@ def test_depth_sweep_k1_full_width(dit48):
     _record("depth_sweep_k1", rows)
     for depth, r in rows.items():
         # the HIP path must sit no further from the fp32 truth than ~the oracle's own bf16 emulation does (x1.5 + 1e-3)
-        assert r["hip_vs_oracle_fp32"] < 1.5 * r["oracle_bf16pts_vs_fp32"] + 1e-3, (depth, r)
-        assert r["hip_vs_oracle_bf16pts"] < 3e-2, (depth, r)
+        assert r["hip_vs_oracle_fp32"] < 1.5 * r["oracle_bf16pts_vs_fp32"] + 1e-3, (depth, r)              # (a)
+        assert r["hip_vs_oracle_bf16pts"] < 1.5 * _MEASURED_R2["depth_sweep_k1"][depth], (depth, r)          # (b)
 
 
 def test_k2_full_depth_cfg_step_vs_oracle_and_cached_equals_pinned(dit48):
@@ -226,17 +251,23 @@ def test_k2_full_depth_cfg_step_vs_oracle_and_cached_equals_pinned(dit48):
     pred = D.dit_forward(P, cfg, x_in, t_in, torch.cat([ne, pe]), torch.cat([nm, pm]), 0, bf16=True)
     v = PO.cfg_zero_star(pred[1:2], pred[0:1], 4.0)
     ref = PO.euler_update(lat, v, float(sig[1]) - float(sig[0]))
+    pred32 = D.dit_forward(P, cfg, x_in, t_in, torch.cat([ne, pe]), torch.cat([nm, pm]), 0, bf16=False)   # fp32 ground truth
     with torch.no_grad():
         got_pred = dit48(hidden_states=x_in.to(BF16), timestep=t_in.to(BF16), encoder_hidden_states=torch.cat([ne, pe]),
                          encoder_attention_mask=torch.cat([nm, pm]), num_cond_latents=0)
     e_pred = rel_l2(got_pred, pred)
+    e_pred32, own = rel_l2(got_pred, pred32), rel_l2(pred, pred32)
     e_upd = rel_l2(out - lat, ref - lat)
     e_lat = rel_l2(out, ref)
-    print(f"K2 depth 48: prediction rel-L2 {e_pred:.2e}, step update rel-L2 {e_upd:.2e}, latents rel-L2 {e_lat:.2e}")
-    _record("k2_depth48_cfg_step", {"pred_rel_l2": e_pred, "update_rel_l2": e_upd, "latents_rel_l2": e_lat})
+    print(f"K2 depth 48: prediction HIP-vs-oracle(bf16 points) {e_pred:.2e}, HIP-vs-fp32 {e_pred32:.2e}, oracle bf16-vs-fp32 {own:.2e}; "
+          f"step update rel-L2 {e_upd:.2e}, latents rel-L2 {e_lat:.2e}")
+    _record("k2_depth48_cfg_step", {"pred_rel_l2": e_pred, "pred_hip_vs_fp32": e_pred32, "pred_oracle_bf16_vs_fp32": own,
+                                    "update_rel_l2": e_upd, "latents_rel_l2": e_lat})
     assert torch.equal(lat, torch.randn(1, 16, 13, 60, 104, generator=torch.Generator().manual_seed(42)).to(DEV))  # input untouched
-    assert e_pred < 3e-2 and e_upd < 5e-2 and e_lat < 2e-3
-    del pred, v, ref, got_pred, x_in
+    m = _MEASURED_R2["k2_depth48_cfg_step"]
+    assert e_pred32 < 1.5 * own + 1e-3                                                                       # (a)
+    assert e_pred < 1.5 * m["pred"] and e_upd < 1.5 * m["update"] and e_lat < 1.5 * m["latents"]             # (b)
+    del pred, pred32, v, ref, got_pred, x_in
     torch.cuda.empty_cache()
     # conditioning frames: KV cache of one t = 0 pass == frames pinned in the sequence (4 cond + 9 noise latent frames)
     a = pipe.denoise(lat, pe, pm, ne, nm, num_cond_latents=4, num_inference_steps=50, use_kv_cache=True, stop_step=1)
@@ -245,7 +276,7 @@ def test_k2_full_depth_cfg_step_vs_oracle_and_cached_equals_pinned(dit48):
     e_kv = rel_l2(a[:, :, 4:] - lat[:, :, 4:], b[:, :, 4:] - lat[:, :, 4:])
     print(f"K2 depth 48: KV-cached vs pinned conditioning, step update rel-L2 {e_kv:.2e}")
     _record("k2_depth48_cached_vs_pinned_update_rel_l2", e_kv)
-    assert e_kv < 3e-2
+    assert e_kv < 7.5e-7        # the same kernels on the same rows: bit-identical (0.0, end of round 2) or a split-K tail's summation order (5.0e-7, mid round 2)
 
 
 def test_k3_full_depth_forward_vs_oracle(dit48):
@@ -257,11 +288,16 @@ def test_k3_full_depth_forward_vs_oracle(dit48):
     ts = torch.full((1, 13), 999.0).to(BF16).to(DEV)
     with torch.no_grad():
         got = dit48(hidden_states=hs, timestep=ts, encoder_hidden_states=pe, encoder_attention_mask=pm, num_cond_latents=0)
-    ref = D.dit_forward(_P(dit48, DEV), cfg, hs, ts, pe, pm, 0, bf16=True)
-    e = rel_l2(got, ref)
-    print(f"K3 depth 48: prediction rel-L2 vs oracle {e:.2e}")
+    P = _P(dit48, DEV)
+    ref = D.dit_forward(P, cfg, hs, ts, pe, pm, 0, bf16=True)
+    ref32 = D.dit_forward(P, cfg, hs, ts, pe, pm, 0, bf16=False)
+    e, e32, own = rel_l2(got, ref), rel_l2(got, ref32), rel_l2(ref, ref32)
+    print(f"K3 depth 48: prediction HIP-vs-oracle(bf16 points) {e:.2e}, HIP-vs-fp32 {e32:.2e}, oracle bf16-vs-fp32 {own:.2e}")
     _record("k3_depth48_forward_rel_l2", e)
-    assert torch.isfinite(got).all() and e < 3e-2
+    _record("k3_depth48_forward", {"hip_vs_oracle_bf16pts": e, "hip_vs_oracle_fp32": e32, "oracle_bf16pts_vs_fp32": own})
+    assert torch.isfinite(got).all()
+    assert e32 < 1.5 * own + 1e-3                                     # (a)
+    assert e < 1.5 * _MEASURED_R2["k3_depth48_forward"]               # (b)
 
 
 def test_text_tokens_zero_pad_branch_matches_oracle():
@@ -289,4 +325,5 @@ def test_text_tokens_zero_pad_branch_matches_oracle():
     ref_off = D.dit_forward(P, cfg_off, hs, ts, y, mask, 1, bf16=True)
     e = rel_l2(got, ref)
     print(f"zero-pad branch rel-L2 {e:.2e}; distance between the two branches {rel_l2(ref, ref_off):.2e}")
-    assert e < 1e-2 and rel_l2(ref, ref_off) > 5 * e      # the branch is really taken (packing would give ref_off)
+    _record("zero_pad_branch_rel_l2", e)
+    assert e < 1.5 * _MEASURED_R2["zero_pad_branch"] and rel_l2(ref, ref_off) > 5 * e      # the branch is really taken (packing would give ref_off)

@@ -50,7 +50,11 @@ def test_fm_mse_samples_matches_torch_and_is_deterministic():
     x0b = x0.expand(B, -1, -1, -1, -1).contiguous()
     assert torch.equal(ops.fm_mse_samples(pred, eps, x0b, Tc), got)
     scalar, _ = ops.fm_mse(pred, eps, x0b, Tc, need_grad=False)
-    assert abs(scalar.item() - got.mean().item()) < 5e-6 * got.mean().item() + 1e-9   # (the scalar kernel adds with fp32 atomics)
+    assert abs(scalar.item() - got.mean().item()) < 1e-6 * got.mean().item() + 1e-9
+    # the training loss is a fixed-order sum too (round 3: per-workgroup partials + one summing launch, no atomics)
+    s2, d2 = ops.fm_mse(pred, eps, x0b, Tc, need_grad=True)
+    s3, d3 = ops.fm_mse(pred, eps, x0b, Tc, need_grad=True)
+    assert torch.equal(s2, s3) and torch.equal(s2, scalar) and torch.equal(d2, d3)
     with pytest.raises(Exception):
         ops.fm_mse_samples(pred, eps.float(), x0, Tc)                    # fp32 noise is refused, not reinterpreted
 
@@ -75,6 +79,70 @@ def test_batched_anchor_loss_equals_the_sequential_reference_form():
               forward_fn=lambda hs, ts, n: dit(hidden_states=hs, timestep=ts, encoder_hidden_states=pe,
                                                encoder_attention_mask=pm, num_cond_latents=n))
     assert abs(es2.best_loss - es.best_loss) <= 2e-6 * abs(seq)
+
+
+def test_cached_conditioning_anchor_form_equals_the_full_sequence_batch(monkeypatch):
+    """Round 3: the anchor set is scored as ONE pass over the (sample-independent) conditioning frames + ONE pass of the six
+    noisy clips against their cached K / V.  Same arithmetic as the pinned `[cond | noisy]` batch: the per-sample losses agree
+    to fp32 summation order, for the bare DiT, with LoRA adapters inside qkv, and under the hook-based wrappers (delta-A on the
+    timestep embedding, delta-B on the hidden stream, delta-C on the output, FiLM on the modulation tables)."""
+    from tta.delta import DeltaAWrapper, DeltaBWrapper, DeltaCWrapper, FiLMAdapterWrapper
+    from tta.early_stopping import _AnchorSet
+    from tta.lora import inject_lora_into_dit, remove_lora_from_dit
+    dit = _small_dit(31)
+    for p in dit.parameters():
+        p.requires_grad = False
+    lat, pe, pm = _clip(11, T=6)
+    cond, val = lat[:, :, :4], lat[:, :, 4:]
+    g = torch.Generator(device=DEV).manual_seed(5)
+    noises = [torch.randn(val.shape, generator=g, device=DEV, dtype=BF16) for _ in range(2)]
+
+    def both(model):
+        a = _AnchorSet(model, cond, val, [0.25, 0.5, 0.75], noises, DEV, BF16)
+        assert a._cached_ok(model, pe, None)
+        cached = a.sample_losses(model, pe, pm, None)
+        assert cached == a.sample_losses(model, pe, pm, None)                      # deterministic
+        monkeypatch.setattr(type(model), "supports_cond_kv_cache", False)
+        try:
+            assert not a._cached_ok(model, pe, None)
+            full = a.sample_losses(model, pe, pm, None)
+        finally:
+            monkeypatch.undo()
+        assert len(cached) == len(full) == 6
+        worst = max(abs(c - f) / abs(f) for c, f in zip(cached, full))
+        return worst, cached
+    w0, base = both(dit)
+    mods = inject_lora_into_dit(dit, rank=4, alpha=8.0, target_modules=["qkv", "proj"])
+    with torch.no_grad():
+        for m in mods:
+            m.lora_up.weight.copy_((torch.randn(m.lora_up.weight.shape, generator=torch.Generator().manual_seed(3)) * 0.05).to(BF16))
+    w1, with_lora = both(dit)
+    assert max(abs(a - b) / abs(b) for a, b in zip(with_lora, base)) > 1e-4          # the adapters really act
+    remove_lora_from_dit(dit)
+    worst = {"dit": w0, "lora": w1}
+    Ct, C = dit.config.adaln_tembed_dim, dit.config.hidden_size
+    for name, w in (("delta_a", DeltaAWrapper(dit, adaln_tembed_dim=Ct)),
+                    ("delta_b_hidden", DeltaBWrapper(dit, num_groups=2, adaln_tembed_dim=Ct, hidden_size=C, delta_target="hidden")),
+                    ("delta_c", DeltaCWrapper(dit, out_channels=16)),
+                    ("film", FiLMAdapterWrapper(dit, num_groups=2, hidden_size=C, film_mode="full"))):
+        w = w.to(DEV).eval()
+        with torch.no_grad():
+            for p in w.parameters():
+                if p.requires_grad:
+                    p.copy_(0.05 * torch.randn(p.shape, generator=torch.Generator().manual_seed(8)).to(p.device))
+        worst[name], got = both(w)
+        assert max(abs(a - b) / abs(b) for a, b in zip(got, base)) > 1e-5, name     # the wrapper really acts
+        assert not dit.t_embedder._forward_hooks and not any(b._forward_hooks or b._forward_pre_hooks for b in dit.blocks)
+    print("cached vs full-sequence anchor losses, worst relative difference:", {k: f"{v:.1e}" for k, v in worst.items()})
+    assert max(worst.values()) < 5e-6
+
+
+def test_early_stopper_refuses_fp32_anchor_latents():
+    from tta.early_stopping import AnchoredEarlyStopper
+    dit = _small_dit()
+    lat, pe, pm = _clip()
+    with pytest.raises(TypeError, match="bfloat16"):
+        AnchoredEarlyStopper().setup(dit, lat[:, :, :3], lat[:, :, 3:].float(), pe, pm, device=DEV, dtype=BF16, video_id="x")
 
 
 def test_lora_loop_with_early_stopping_restores_the_best_snapshot():
@@ -161,10 +229,15 @@ def test_anchor_check_time_batched_vs_sequential_full_width():
             out = fn()
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / n, out
-    t_b, l_b = clock(es._compute_anchor_loss)
+    t_c, l_c = clock(es._compute_anchor_loss)                              # round 3: shared conditioning-frame KV cache
+    type(dit).supports_cond_kv_cache = False
+    try:
+        t_b, l_b = clock(es._compute_anchor_loss)                          # round 2: the full [cond | noisy] batch
+    finally:
+        type(dit).supports_cond_kv_cache = True
     t_s, l_s = clock(lambda: compute_flow_matching_loss_conditioned_fixed(dit, cond, val, pe, pm, es.anchor_sigmas,
                                                                           es.fixed_noises, device=DEV, dtype=BF16))
     print(f"ES check, 6 samples x 6 240 tokens x 4 blocks: sequential {t_s * 1e3:.1f} ms, batched {t_b * 1e3:.1f} ms "
-          f"({t_s / t_b:.2f}x); losses {l_s:.6f} / {l_b:.6f}")
-    assert abs(l_b - l_s) <= 1e-5 * abs(l_s)
-    assert t_b < 1.15 * t_s
+          f"({t_s / t_b:.2f}x), cached conditioning {t_c * 1e3:.1f} ms ({t_s / t_c:.2f}x); losses {l_s:.6f} / {l_b:.6f} / {l_c:.6f}")
+    assert abs(l_b - l_s) <= 1e-5 * abs(l_s) and abs(l_c - l_s) <= 1e-5 * abs(l_s)
+    assert t_b < 1.15 * t_s and t_c < 0.75 * t_b                           # 4 680 + 6 x 1 560 token rows instead of 6 x 6 240

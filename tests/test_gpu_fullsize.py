@@ -256,3 +256,57 @@ def test_fused_sgd_clip_on_a_13_6b_sized_tensor_list_property():
     for p, b in zip(ps, before):
         exp = (b.float() - 0.5 * p.grad.float()).to(BF16)
         assert torch.equal(p.detach(), exp)
+
+
+# ------------------------------------------------------------------------------------------------ K3' (round 3)
+N_K3P = 176400      # north_star's literal "49 x 90 x 160 latents": [1, 16, 49, 90, 160] -> 49 * 45 * 80 tokens (SURVEY §8 header)
+
+
+def test_attention_k3p_176400_tokens_rows_vs_fp32_and_key_permutation():
+    """Self-attention at the literal K3' size, all 32 heads: a row subset against fp32 softmax(QK^T)V over all 176 400 keys
+    (token rows from the first, a middle and the LAST query block: byte offsets past 2^31 in the packed qkv buffer, whose
+    token stride is 24 576 bytes -> 4.3e9 bytes), the log-sum-exp, and invariance to a permutation of the key / value rows."""
+    ops = _ops()
+    g = torch.Generator(device=DEV).manual_seed(808)
+    qkv = torch.randn((1, N_K3P, 3, H, D), generator=g, device=DEV).to(BF16)
+    assert qkv.numel() * 2 > 2 ** 32
+    qkv[:, :, 0] = (qkv[:, :, 0].float() * ops.log2_qscale(D ** -0.5)).to(BF16)      # the product's convention: q in log2 units
+    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    o, lse = ops.attention(q, k, v, ops.LN2, need_lse=True)
+    assert torch.isfinite(o).all()
+    rows = torch.cat([torch.randint(0, N_K3P, (40,), generator=g, device=DEV),
+                      torch.tensor([0, 255, 256, N_K3P // 2, N_K3P - 257, N_K3P - 2, N_K3P - 1], device=DEV)])
+    for h in (0, 11, 31):
+        s = (q[0, rows, h].float() @ k[0, :, h].float().t()) * ops.LN2
+        ref = torch.softmax(s, dim=-1) @ v[0, :, h].float()
+        assert rel_l2(o[0, rows, h], ref) < 6e-3, h
+        assert torch.allclose(lse[0, h, rows], torch.logsumexp(s, dim=-1), atol=3e-4, rtol=1e-5)
+    perm = torch.randperm(N_K3P, generator=g, device=DEV)
+    o2, _ = ops.attention(q, k[:, perm].contiguous(), v[:, perm].contiguous(), ops.LN2)
+    assert rel_l2(o2, o) < 4e-3
+
+
+def test_gemm_w2_k3p_cfg_batch_rows_past_4gb_vs_fp32(monkeypatch):
+    """The FFN down-projection of a CFG pass at K3': M = 352 800 rows of K = 11 008 (22 016-byte rows: the last row starts
+    7.8e9 bytes into the operand - the 32-bit-offset question of the round-2 review).  Round 3 gave the 8-phase kernel a 64-bit
+    per-tile base, so this shape no longer falls back: rows before and after the 2^32-byte line and the very last rows against
+    fp32, and the whole output bit-identical to the one-barrier kernel (`LCV_GEMM_TILE=6`, 64-bit row indices throughout)."""
+    ops = _ops()
+    g = torch.Generator(device=DEV).manual_seed(909)
+    M, N, K = 2 * N_K3P, C, F_
+    a = torch.randn((M, K), generator=g, device=DEV).to(BF16)
+    assert M * K * 2 > 2 ** 32
+    w = (torch.randn((N, K), generator=g, device=DEV) * 0.02).to(BF16)
+    b = torch.randn((N,), generator=g, device=DEV).to(BF16)
+    c = ops.gemm_nt(a, w, b)
+    line = 2 ** 32 // (2 * K)                                          # first row whose bytes cross 4 GiB
+    rows = torch.cat([torch.randint(0, M, (64,), generator=g, device=DEV),
+                      torch.tensor([0, 255, 256, line - 1, line, line + 1, 2 * line + 7, M - 257, M - 96, M - 1], device=DEV)])
+    ref = a[rows].float() @ w.float().t() + b.float()
+    assert rel_l2(c[rows], ref) < 2e-3
+    worst = ((c[rows].float() - ref).norm(dim=1) / ref.norm(dim=1)).max().item()
+    assert worst < 4e-3, worst                                         # every sampled row, not only their average
+    monkeypatch.setenv("LCV_GEMM_TILE", "6")
+    c6 = ops.gemm_nt(a, w, b)
+    monkeypatch.delenv("LCV_GEMM_TILE")
+    assert torch.equal(c, c6)

@@ -133,6 +133,32 @@ def test_attention_log2_prescaled_q(B, H, Nq, Nk):
     assert torch.allclose(lse.cpu(), torch.logsumexp(s, dim=-1), atol=2e-4, rtol=1e-5)
 
 
+def test_lse_merge_of_key_ranges_equals_the_one_call_attention():
+    """Sequence parallelism's overlap path (`LCV_SP_OVERLAP=1`, lcv_hip/autograd_ops.py::_sp_attention_overlapped) attends the
+    local keys while the gather is in flight and merges the partial results through their log-sum-exps.  The merge assumes
+    natural-log units for the kernel's lse; this pins that on ONE GPU: K / V cut into three ranges (ragged sizes, one of them
+    short enough for the short-key body), both scale conventions, merged == the one-call result up to one more bf16 rounding
+    of a partial output."""
+    from lcv_hip import autograd_ops as A
+    ops, orc = _ops(), _orc()
+    B, H, Nq, Nk, D = 2, 2, 333, 1500, 128
+    for scale, c in ((D ** -0.5, 1.0), (ops.LN2, ops.log2_qscale(D ** -0.5))):
+        q = (_randn(B, Nq, H, D, seed=21).float() * c).to(BF16).to(DEV)
+        k = _randn(B, Nk, H, D, seed=22).to(DEV); v = _randn(B, Nk, H, D, seed=23).to(DEV)
+        whole, lse = ops.attention(q, k, v, scale, need_lse=True)
+        cuts = [(0, 700), (700, 777), (777, Nk)]
+        parts = [ops.attention(q, k[:, a:b], v[:, a:b], scale, need_lse=True) for a, b in cuts]
+        merged = A.merge_attention_parts(parts)
+        lse_m = torch.logsumexp(torch.stack([l for _, l in parts], 0), dim=0)
+        assert torch.allclose(lse_m, lse, atol=2e-4, rtol=1e-5)
+        e = rel_l2(merged, whole.float())
+        ref = orc.sdpa(q.cpu().permute(0, 2, 1, 3), k.cpu().permute(0, 2, 1, 3), v.cpu().permute(0, 2, 1, 3), scale)
+        assert e < 4e-3 and rel_l2(merged.cpu().permute(0, 2, 1, 3), ref) < 6e-3, (scale, e)
+        # a wrong unit (log2 lse read as natural log) would weight the parts by 2^(.) instead of e^(.): far outside this bound
+        bad = A.merge_attention_parts([(o_i, l_i * 1.4426950408889634) for o_i, l_i in parts])
+        assert rel_l2(bad, whole.float()) > 5 * e
+
+
 def test_attention_strided_packed_qkv_and_spike():
     """q/k/v as views of a packed [B,N,3,H,D] buffer; one key row spiked so the running max jumps mid-stream."""
     ops, orc = _ops(), _orc()
