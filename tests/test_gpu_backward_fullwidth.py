@@ -173,9 +173,9 @@ def test_full_width_lora_gradients_k1_tokens(dit2_lora, ncond):
     cfg = _cfg(2)
     inp = _inputs(5, 32, 32, ncond, 431.0)
     row, *_ = _compare(f"i_k1_depth2_ncond{ncond}", m, mods, _adapter_names(2, False), cfg, inp, ncond)
-    # measured (round 3, depth 2): see DESIGN.md §3; bounds = 1.5 x measured, rounded up
-    assert row["loss_rel"] < 3e-3
-    assert row["grad_rel_l2_max"] < 2.5e-2 and row["grad_rel_l2_median"] < 1.2e-2
+    # measured (round 3): loss 8.6e-5 / 8.5e-6 relative, gradients max 1.82e-2 / 1.69e-2 (cross_attn.q_linear.A), median 4.2e-3
+    assert row["loss_rel"] < 4.4e-4
+    assert row["grad_rel_l2_max"] < 2.7e-2 and row["grad_rel_l2_median"] < 6.3e-3
 
 
 def test_full_width_lora_gradients_k1_tokens_with_ffn_adapters():
@@ -185,8 +185,8 @@ def test_full_width_lora_gradients_k1_tokens_with_ffn_adapters():
     cfg = _cfg(2)
     inp = _inputs(5, 32, 32, 2, 612.0, seed=31)
     row, *_ = _compare("i_k1_depth2_ncond2_ffn", m, mods, _adapter_names(2, True), cfg, inp, 2)
-    assert row["loss_rel"] < 3e-3
-    assert row["grad_rel_l2_max"] < 2.5e-2 and row["grad_rel_l2_median"] < 1.2e-2
+    assert row["loss_rel"] < 4.4e-4                                    # measured 5.7e-5; gradients max 7.5e-3, median 3.0e-3
+    assert row["grad_rel_l2_max"] < 1.1e-2 and row["grad_rel_l2_median"] < 4.5e-3
 
 
 # ------------------------------------------------------------------------------------------------ (ii) 6 240 tokens
@@ -198,8 +198,8 @@ def test_full_width_lora_gradients_reference_operating_point(dit2_lora):
     inp = _inputs(4, 60, 104, 3, 777.0, seed=32)
     row, *_ = _compare("ii_480p_6240tok_depth2_ncond3", m, mods, _adapter_names(2, False), cfg, inp, 3)
     assert row["tokens"] == 6240
-    assert row["loss_rel"] < 3e-3
-    assert row["grad_rel_l2_max"] < 2.5e-2 and row["grad_rel_l2_median"] < 1.2e-2
+    assert row["loss_rel"] < 4.4e-4                                    # measured 2.9e-4; gradients max 7.9e-3, median 3.9e-3
+    assert row["grad_rel_l2_max"] < 1.2e-2 and row["grad_rel_l2_median"] < 5.9e-3
 
 
 # ------------------------------------------------------------------------------------------------ (iii) depth sweep
@@ -236,9 +236,11 @@ def test_full_width_lora_gradient_depth_sweep():
         m.blocks = blocks
     for depth, r in rows.items():
         # the HIP backward sits no further from the fp32 truth than ~the oracle's own bf16 evaluation does
-        assert r["grad_rel_l2_max"] < 1.5 * r["oracle_bf16_vs_fp32_max"] + 2e-3, (depth, r)
-        assert r["grad_rel_l2_median"] < 1.5 * r["oracle_bf16_vs_fp32_median"] + 2e-3, (depth, r)
-        assert r["loss_rel"] < 1.5e-2, (depth, r)
+        # measured (HIP / oracle-bf16, max | median): depth 2 9.1e-3 / 8.8e-3 | 4.0e-3 / 3.4e-3; depth 8 1.35e-2 / 1.27e-2 | 4.8e-3 /
+        # 4.4e-3; depth 48 2.49e-2 / 2.54e-2 | 1.03e-2 / 1.01e-2; loss 2.0e-4 ... 5.5e-4 relative
+        assert r["grad_rel_l2_max"] < 1.5 * r["oracle_bf16_vs_fp32_max"] + 1e-3, (depth, r)
+        assert r["grad_rel_l2_median"] < 1.5 * r["oracle_bf16_vs_fp32_median"] + 1e-3, (depth, r)
+        assert r["loss_rel"] < 8.3e-4, (depth, r)
 
 
 # ------------------------------------------------------------------------------------------------ (iv) three inner steps
@@ -288,7 +290,7 @@ def test_three_full_width_inner_steps_match_oracle_adamw():
         loss.backward()
         ref_norms.append(float(torch.nn.utils.clip_grad_norm_(ref, clip)))
         ropt.step()
-        ref_losses.append(float(loss))
+        ref_losses.append(float(loss.detach()))
         del P2, pred, loss
 
     # ---- the product's run, same sigma / noise draws injected
@@ -323,7 +325,10 @@ def test_three_full_width_inner_steps_match_oracle_adamw():
           f"adapter weights rel-L2 max {row['weights_rel_l2_max']:.2e}; update rel-L2 max {row['update_rel_l2_max']:.2e} "
           f"median {row['update_rel_l2_median']:.2e}; within 1 ulp {row['frac_within_1ulp']:.4f}, 2 ulp {row['frac_within_2ulp']:.4f}")
     _record("iv_three_inner_steps_k1_depth2", row)
-    assert max(loss_rel) < 5e-3
-    # Adam's first steps move every element by ~lr * sign(g): an element whose (tiny) gradient changes sign between the two
-    # implementations ends 2 lr apart.  Measured fractions / distances in DESIGN.md §3; bounds 1.5 x measured.
-    assert row["weights_rel_l2_max"] < 2e-2 and row["frac_within_2ulp"] > 0.90
+    # measured (round 3): losses within 1.0e-4 / 1.7e-4 / 1.7e-4 relative; adapter weights rel-L2 max 1.12e-3; 98.73 % of the
+    # 852 k adapter elements within one bf16 ulp, 99.46 % within two.  Adam's first steps move every element by ~lr * sign(g):
+    # an element whose (tiny) gradient changes sign between the two implementations ends up to 2 lr apart - the rest of the
+    # distribution, and why the rel-L2 of the accumulated UPDATE (3.1e-2 median, 5.9e-2 max) is larger than that of the weights.
+    assert max(loss_rel) < 2.6e-4
+    assert row["weights_rel_l2_max"] < 1.7e-3 and row["update_rel_l2_max"] < 8.8e-2 and row["update_rel_l2_median"] < 4.6e-2
+    assert row["frac_within_1ulp"] > 0.981 and row["frac_within_2ulp"] > 0.9919
