@@ -42,12 +42,16 @@ __device__ __forceinline__ int swz_k2(int row) { return ((row & 3) << 2) | ((row
 // PIPE: the fragment reads of k-step ks+1 (and of transposed-read step j+1) are issued BEFORE the MFMAs of step ks (j), pinned
 // with scheduling fences.  hipcc's own order is {3 reads; wait; 2 MFMAs} x 8 - every MFMA pair behind a full LDS latency,
 // which the partner wave only half hides (matrix pipe 0.47 busy, profiles/r02_attn_pmc_summary.md).
-template <bool PIPE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dkv2_kernel(const AttnBwdDkv2Params p) {
+// NW: waves per workgroup = 32 * NW keys per block.  NW = 4: two workgroups per CU (above).  NW = 8 (round 3, LCV_ATTN_BWD_DKV_WAVES=8): ONE
+// 8-wave workgroup per CU owns 256 keys, so a Q / dO tile staged into LDS feeds twice the MFMAs: 16 KiB of LDS-DMA fill per 256
+// MFMAs instead of per 128 (at the MFMA rate that is 8 instead of 16 B/clk per CU against the ~20-25 B/clk the fill path delivers).
+template <bool PIPE, int NW = 4>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dkv2_kernel(const AttnBwdDkv2Params p) {
   constexpr int QT = 32;
+  constexpr int NP = 8 / NW;                            // one-KiB Q (and dO) pieces per wave and tile
   constexpr int TILE_BYTES = QT * 256;                  // one [32][128] bf16 tile
   constexpr int STAGE = 2 * TILE_BYTES + 2 * QT * 4;    // Q | dO | -lse | -delta
-  constexpr int K_BYTES = 128 * 256;                    // the block's K rows
+  constexpr int K_BYTES = NW * 32 * 256;                // the block's K rows
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   lds_u8* lds_k = (lds_u8*)smem;
   lds_u8* lds = lds_k + K_BYTES;                        // [2] stages
@@ -70,7 +74,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   } else {
     kb = blockIdx.x; head = blockIdx.y; b = blockIdx.z;
   }
-  const int64_t key0 = (int64_t)kb * 128;
+  const int64_t key0 = (int64_t)kb * (NW * 32);
   const bf16_t* kbase = p.k + b * p.k_sb + (int64_t)head * p.k_sh;
 
   // ---- V rows of this lane's key as B operands (registers); K rows of the whole block -> LDS by DMA ----
@@ -97,11 +101,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int64_t Nqp = (p.Nq + 31) / 32 * 32;
   const char* cbase_u = lcv_uniform_ptr(p.consts + (b * p.H + head) * 2 * Nqp);
   const unsigned coff = (unsigned)((lane < 32 ? lane : Nqp + lane - 32) * 4);   // one dword piece: 32 x nlse2 | 32 x ndelta
-  int dma_row[2];
-  unsigned qoff[2], dooff[2];
+  int dma_row[NP];
+  unsigned qoff[NP], dooff[NP];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    dma_row[i] = 8 * wave + 4 * i + (lane >> 4);
+  for (int i = 0; i < NP; ++i) {
+    dma_row[i] = 4 * (NP * wave + i) + (lane >> 4);
     const int col = 8 * ((lane & 15) ^ swz_k2(dma_row[i]));
     qoff[i] = (unsigned)((dma_row[i] * p.q_sn + col) * 2);
     dooff[i] = (unsigned)((dma_row[i] * p.o_sn + col) * 2);
@@ -112,18 +116,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   auto load_tile = [&](int64_t q0, int buf) {
     // asm-issued (lcv_common.h: a builtin DMA would be waited for before the next fragment read); waited for before the barrier.
     // Source = scalar tile base + a per-lane 32-bit offset that never changes; the ragged last tile clamps rows per lane.
-    const unsigned sb = stage_addr0 + (unsigned)(buf * STAGE) + (unsigned)wave * 2048u;
+    const unsigned sb = stage_addr0 + (unsigned)(buf * STAGE) + (unsigned)wave * (unsigned)(NP * 1024);
     const char* qt = qbase_u + q0 * (2 * p.q_sn);
     const char* dt = dobase_u + q0 * (2 * p.o_sn);
     if (q0 + QT <= p.Nq) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < NP; ++i) {
         lcv_lds_dma16_sv(qoff[i], qt, sb + 1024u * i);
         lcv_lds_dma16_sv(dooff[i], dt, sb + (unsigned)TILE_BYTES + 1024u * i);
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < NP; ++i) {
         int64_t back = q0 + dma_row[i] - (p.Nq - 1);
         if (back < 0) back = 0;
         lcv_lds_dma16(qt + qoff[i] - back * p.q_sn * 2, sb + 1024u * i);
@@ -312,11 +316,15 @@ int attn_bwd_dkv2_launch(const void* q, const void* k, const void* v, const void
   p.v_sb = v_sb; p.v_sn = v_sn; p.v_sh = v_sh; p.o_sb = o_sb; p.o_sn = o_sn; p.o_sh = o_sh;
   p.dk_sb = dk_sb; p.dk_sn = dk_sn; p.dk_sh = dk_sh; p.dv_sb = dv_sb; p.dv_sn = dv_sn; p.dv_sh = dv_sh;
   p.scale = scale; p.accumulate_kv = accumulate_kv;
-  const size_t lds = 128 * 256 + 2 * (2 * 32 * 256 + 2 * 32 * 4);
+  const char* we = getenv("LCV_ATTN_BWD_DKV_WAVES");   // A/B knob: 4 = two 4-wave workgroups per CU (128 keys each), 8 = one 8-wave (256 keys)
+  const int nw = (we && we[0] == '8') ? 8 : 4;
+  const size_t lds = (size_t)nw * 32 * 256 + 2 * (2 * 32 * 256 + 2 * 32 * 4);
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)attn_bwd_dkv2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-        hipFuncSetAttribute((const void*)attn_bwd_dkv2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    const int l4 = 4 * 32 * 256 + 2 * (2 * 32 * 256 + 2 * 32 * 4), l8 = 8 * 32 * 256 + 2 * (2 * 32 * 256 + 2 * 32 * 4);
+    if (hipFuncSetAttribute((const void*)attn_bwd_dkv2_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, l4) != hipSuccess ||
+        hipFuncSetAttribute((const void*)attn_bwd_dkv2_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, l4) != hipSuccess ||
+        hipFuncSetAttribute((const void*)attn_bwd_dkv2_kernel<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, l8) != hipSuccess) {
       lcv_set_error("attn_bwd: cannot raise dynamic LDS");
       return LCV_EDEVICE;
     }
@@ -325,15 +333,16 @@ int attn_bwd_dkv2_launch(const void* q, const void* k, const void* v, const void
   { const char* se = getenv("LCV_ATTN_BWD_STAGGER"); p.stagger = se ? atoi(se) : 0; if (p.stagger < 0 || p.stagger > 127) p.stagger = 0; }
   const char* pe = getenv("LCV_ATTN_BWD_PIPE");   // A/B knob: 0 = hipcc's own read / MFMA order
   const bool pipe = !(pe && pe[0] == '0');
-  const unsigned gx = (unsigned)((Nk + 127) / 128);
+  const unsigned gx = (unsigned)((Nk + nw * 32 - 1) / (nw * 32));
   // A/B knob LCV_ATTN_BWD_XCD=1 enables the head-per-XCD block order.  OFF by default: at the K3-TTA shapes (25 200 keys x 32
   // heads) it measured 27.06 vs 26.51 ms per layer in one process - unlike the forward, these passes are not helped by it
   const char* xe = getenv("LCV_ATTN_BWD_XCD");
   p.gx = (int)gx;
   p.xcd_remap = ((B * H) % 8 == 0 && gx >= 8 && xe && xe[0] == '1') ? 1 : 0;
   const dim3 grid = p.xcd_remap ? dim3(gx * (unsigned)(H * B)) : dim3(gx, (unsigned)H, (unsigned)B);
-  if (pipe) hipLaunchKernelGGL(attn_bwd_dkv2_kernel<true>, grid, dim3(256), lds, s, p);
-  else hipLaunchKernelGGL(attn_bwd_dkv2_kernel<false>, grid, dim3(256), lds, s, p);
+  if (nw == 8) hipLaunchKernelGGL((attn_bwd_dkv2_kernel<true, 8>), grid, dim3(512), lds, s, p);
+  else if (pipe) hipLaunchKernelGGL((attn_bwd_dkv2_kernel<true, 4>), grid, dim3(256), lds, s, p);
+  else hipLaunchKernelGGL((attn_bwd_dkv2_kernel<false, 4>), grid, dim3(256), lds, s, p);
   LCV_LAUNCH_CHECK("attn_bwd_dkv2");
   return LCV_OK;
 }

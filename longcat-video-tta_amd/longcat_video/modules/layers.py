@@ -152,14 +152,14 @@ class Attention(nn.Module):
         return out
 
     def _forward_sequence_parallel(self, qkv, shape, num_cond_latents, sp, fuse_residual=None):
-        """Frame-sharded tokens: RoPE at GLOBAL positions, all-gather of K/V (post-norm, post-RoPE), local-Q x full-KV;
-        `num_cond_latents` is this rank's LOCAL count of conditioning frames (a prefix of its shard), the global count comes
-        from the SP context.  Differentiable (dK / dV are summed over the ranks in the backward)."""
+        """Token-row-sharded tokens: RoPE at GLOBAL positions (the table of the clip's true grid, addressed by the shard's token
+        offset), all-gather of K/V (post-norm, post-RoPE), local-Q x full-KV; `num_cond_latents` counts this rank's LOCAL
+        conditioning units (token rows: a prefix of its shard), the global count comes from the SP context.  Differentiable
+        (dK / dV are summed over the ranks in the backward)."""
         B, N, _, H, D = qkv.shape
-        S = shape[1] * shape[2]
-        cs = self.rope_3d.table((sp.num_frames, shape[1], shape[2]), qkv.device)
-        n_loc = int(num_cond_latents or 0) * S
-        n_glob = int(getattr(sp, "num_cond_frames", 0)) * S
+        cs = self.rope_3d.table(sp.grid, qkv.device)
+        n_loc = int(num_cond_latents or 0) * sp.S
+        n_glob = int(getattr(sp, "num_cond_frames", 0)) * sp.tokens_per_frame
         o = A.sp_self_attention(qkv, self.q_norm.weight, self.k_norm.weight, cs, self.scale, self.q_norm.eps, sp, n_loc, n_glob)
         return _proj_out(self.proj, o.view(B, N, H * D), fuse_residual)
 
@@ -170,11 +170,10 @@ class Attention(nn.Module):
         qkv = self.qkv(x).view(B, N, 3, H, D)
         k_c, v_c = kv_cache
         n_c = k_c.shape[1]
-        T, Hh, Ww = shape
-        t_c = n_c // (Hh * Ww)
         sp = getattr(self, "_sp", None)
-        if sp is not None:  # frame-sharded noise tokens: global RoPE rows, all-gather of the fresh K/V, cond K/V replicated
-            cs = self.rope_3d.table((sp.num_frames + t_c, Hh, Ww), x.device)
+        if sp is not None:  # row-sharded noise tokens: global RoPE rows, all-gather of the fresh K/V, cond K/V replicated
+            t_c = n_c // sp.tokens_per_frame
+            cs = self.rope_3d.table((sp.num_frames + t_c, sp.rows_per_frame, sp.S), x.device)
             q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
             ops.qknorm_rope(q, k, None, q, k, None, self.q_norm.weight, self.k_norm.weight, cs, n_c + sp.token_offset,
                             self.q_norm.eps, q_scale=ops.log2_qscale(self.scale))
@@ -182,6 +181,8 @@ class Attention(nn.Module):
             ex = (lambda t: t if t.shape[0] == B else t.expand(B, -1, -1, -1))
             o, _ = ops.attention(q, torch.cat([ex(k_c), k_full], dim=1), torch.cat([ex(v_c), v_full], dim=1), ops.LN2)
             return _proj_out(self.proj, o.view(B, N, C), fuse_residual)
+        T, Hh, Ww = shape
+        t_c = n_c // (Hh * Ww)
         cs = self.rope_3d.table((T + t_c, Hh, Ww), x.device)
         o = A.cached_attention(qkv, k_c, v_c, self.q_norm.weight, self.k_norm.weight, cs, self.scale,
                                self.q_norm.eps)

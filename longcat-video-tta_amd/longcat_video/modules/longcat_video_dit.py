@@ -177,37 +177,47 @@ class LongCatVideoTransformer3DModel(nn.Module):
         if self._sp_group is None:
             return
         from ..parallel.sequence_parallel import SPContext
-        SPContext(1, 1, self._sp_group[0]).all_reduce_grads(params)
+        SPContext(1, 1, self._sp_group[0]).all_reduce_grads(params)      # (a context for its collective helpers only)
 
     def _forward_sp(self, hidden_states, timestep, encoder_hidden_states, encoder_attention_mask, num_cond_latents,
                     kv_cache_dict=None):
-        """Frame-sharded forward.  Without conditioning frames every rank takes its run of latent frames.  With the
-        conditioning-frame KV cache (`kv_cache_dict`: the cond K/V are small and REPLICATED - every rank computed them with
-        the plain path) the NOISE frames are sharded and each attention layer attends [cached cond | all-gathered noise]."""
+        """Token-row-sharded forward (parallel/sequence_parallel.py).  Every rank takes a contiguous run of token rows and runs
+        the PLAIN forward on it, presented as a clip of one-row frames: latents [B, C, rows, 2, w], one timestep per row, grid
+        (rows, 1, w/2).  Without conditioning frames the whole clip is sharded.  With the conditioning-frame KV cache
+        (`kv_cache_dict`: the cond K/V are small and REPLICATED - every rank computed them with the plain path) the NOISE frames
+        are sharded and each attention layer attends [cached cond | all-gathered noise].  With the conditioning frames pinned in
+        the sequence they are its first rows, possibly split over ranks."""
         from ..parallel.sequence_parallel import SPContext
-        B, _, T, H, W = hidden_states.shape
-        N_h, N_w = H // self.patch_size[1], W // self.patch_size[2]
-        sp = SPContext(T // self.patch_size[0], N_h * N_w, self._sp_group[0])
+        B, C, T, H, W = hidden_states.shape
+        pt, ph, pw = self.patch_size
+        if pt != 1:
+            raise NotImplementedError("sequence parallelism assumes temporal patch size 1")
+        N_h, N_w = H // ph, W // pw
+        sp = SPContext(T, N_h * N_w, self._sp_group[0], rows_per_frame=N_h)
         if len(timestep.shape) == 1:
             timestep = timestep.unsqueeze(1).expand(-1, T)
+        rows = hidden_states.reshape(B, C, T * N_h, ph, W)                     # a view: (H) = (N_h, ph), rows of one token each
+        ts_rows = timestep.repeat_interleave(N_h, dim=1)                       # a frame's rows share its timestep
         for b in self.blocks:
             b.attn._sp = sp
         try:
             self._sp_group, saved = None, self._sp_group      # the local call below is the plain path on this shard
             if kv_cache_dict is not None:
-                ncl_local = num_cond_latents          # cond K/V come from the (replicated) cache; only noise frames are here
-            else:                                     # cond frames pinned in the sequence: the lowest frames, maybe split over ranks
+                ncl_local = num_cond_latents          # cond K/V come from the (replicated) cache; only noise rows are here
+            else:                                     # cond frames pinned in the sequence: its first rows, maybe split over ranks
                 sp.num_cond_frames = int(num_cond_latents or 0)
-                ncl_local = max(0, min(sp.t1, sp.num_cond_frames) - sp.t0)
-            local = self.forward(hidden_states[:, :, sp.t0:sp.t1].contiguous(), timestep[:, sp.t0:sp.t1].contiguous(),
+                ncl_local = sp.local_units_of_leading_frames(sp.num_cond_frames)
+            local = self.forward(rows[:, :, sp.t0:sp.t1].contiguous(), ts_rows[:, sp.t0:sp.t1].contiguous(),
                                  encoder_hidden_states, encoder_attention_mask, ncl_local, kv_cache_dict=kv_cache_dict)
         finally:
             self._sp_group = saved
             for b in self.blocks:
                 b.attn._sp = None
         if torch.is_grad_enabled() and local.requires_grad:
-            return sp.gather_frames_autograd(local)
-        return sp.gather_frames(local)
+            full = sp.gather_frames_autograd(local)                            # [B, C_out, T * N_h, ph, W]
+        else:
+            full = sp.gather_frames(local)
+        return full.reshape(B, full.shape[1], T, H, W)
 
     # ------------------------------------------------------------------ forward
     def forward(self, hidden_states, timestep, encoder_hidden_states, encoder_attention_mask=None,

@@ -1,6 +1,15 @@
-"""Frame-axis sequence parallelism: rank r holds a contiguous run of latent frames (N/W tokens);
-every per-token op is local (the adaLN table is per frame, RoPE uses GLOBAL positions via `pos_off`), and self-attention
-all-gathers K and V (post-norm, post-RoPE) so each rank runs local-Q x full-KV on the flash kernel.
+"""Sequence parallelism over contiguous token runs: rank r holds a contiguous run of the token sequence;
+every per-token op is local (RoPE uses GLOBAL positions via `pos_off`), and self-attention all-gathers K and V (post-norm,
+post-RoPE) so each rank runs local-Q x full-KV on the flash kernel.
+
+Round 3 - the shard unit is a TOKEN ROW (one row of w/2 tokens of one latent frame), not a latent frame.  Whole frames
+cannot balance the headline shape: 49x720p is 13 latent frames, 2,2,2,2,2,1,1,1 over 8 ranks = at most 0.81 efficient, and
+that split has gaps inside the padded sequence (the slow list / concatenate path).  In token rows it is 585 rows of 80
+tokens: 74 x 7 + 67 (5 920 / 5 360 tokens, 0.988 balanced), pads only at the end, the single-collective path - always, for
+any clip with more rows than ranks squared.  Nothing downstream knows: the model sees its shard as a clip of `rows` one-row
+"frames" ([B, C, rows, 2, w] latents, grid (rows, 1, w/2)): the (1, 2, 2) patches never cross a token row, the per-frame
+timestep / adaLN table is expanded to one entry per row (a frame's rows share its values), and RoPE rows are addressed by the
+GLOBAL token offset into the table of the true (T, h/2, w/2) grid.
 
 Collectives (torch.distributed; backend "nccl" = RCCL over xGMI on MI355X, "gloo" in the CPU tests):
   forward   ONE `all_gather_into_tensor` per tensor straight into a [W * n_max, H, D] buffer: every rank but the last
@@ -27,14 +36,18 @@ import torch
 
 
 def frame_shards(num_frames: int, world_size: int) -> List[int]:
-    """Frames per rank.  Preferred: ceil(T / W) on every rank and the remainder on the last (pads only at the end of the
-    gathered sequence); when that would leave a rank empty: as even as possible, larger shards first."""
+    """Units (token rows since round 3; latent frames before) per rank.  Preferred: ceil(U / W) on every rank and the
+    remainder on the last (pads only at the end of the gathered sequence); when that would leave a rank empty: as even as
+    possible, larger shards first."""
     per = math.ceil(num_frames / world_size)
     counts = [min(per, max(0, num_frames - r * per)) for r in range(world_size)]
     if counts[-1] > 0:
         return counts
     base, rem = divmod(num_frames, world_size)
     return [base + (1 if r < rem else 0) for r in range(world_size)]
+
+
+row_shards = frame_shards      # the same rule, counted in token rows
 
 
 def pads_at_end(counts: List[int]) -> bool:
@@ -55,31 +68,61 @@ def _pad_rows(x: torch.Tensor, n_max: int) -> torch.Tensor:
     return out
 
 
-def _gather_rows(x: torch.Tensor, counts: List[int], S: int, group=None, out: torch.Tensor = None) -> torch.Tensor:
-    """All-gather along the token axis; returns [B, N, ...] in frame order (a VIEW of the padded buffer when the pads sit
-    at the end, see `pads_at_end`)."""
+_COALESCE = {"ok": None}      # None = untried; the RCCL backend groups several tensor collectives into one launch, gloo cannot
+
+
+def _gather_many(xs: List[torch.Tensor], counts: List[int], S: int, group=None) -> List[torch.Tensor]:
+    """All-gather several [B, n_local, ...] tensors along the token axis; each result is [B, N, ...] in sequence order (a
+    VIEW of its padded [B, W * n_max, ...] buffer when the pads sit at the end, see `pads_at_end`).
+
+    K and V of BOTH CFG batch elements of a layer are exchanged as ONE grouped launch on RCCL (`_coalescing_manager`: one
+    ncclGroup around the 2 x B `all_gather_into_tensor` calls) - a batch element must land in its own [W * n_max] rows for the
+    attention kernel's (batch, token) strides, so the calls stay separate ops, but not separate launches.  Backends without
+    coalescing (gloo: the CPU tests, ranks sharing one GPU) issue them one after the other; same bytes, same result."""
     import torch.distributed as dist
     world = len(counts)
     n_max = max(counts) * S
     N = sum(counts) * S
-    B = x.shape[0]
-    xp = _pad_rows(x, n_max)
-    if pads_at_end(counts):
-        if out is None:
-            out = torch.empty((B, world * n_max) + tuple(x.shape[2:]), dtype=x.dtype, device=x.device)
-        for b in range(B):                                   # (B = 2 under CFG: two collectives, each into its own rows)
-            dist.all_gather_into_tensor(out[b], xp[b], group=group)
-        return out[:, :N]
-    outs = [torch.empty_like(xp) for _ in range(world)]      # gaps inside the sequence: gather, then drop the pads
-    dist.all_gather(outs, xp, group=group)
-    return torch.cat([o[:, : c * S] for o, c in zip(outs, counts)], dim=1)
+    if not pads_at_end(counts):                                   # gaps inside the sequence: gather, then drop the pads
+        res = []
+        for x in xs:
+            xp = _pad_rows(x, n_max)
+            outs = [torch.empty_like(xp) for _ in range(world)]
+            dist.all_gather(outs, xp, group=group)
+            res.append(torch.cat([o[:, : c * S] for o, c in zip(outs, counts)], dim=1))
+        return res
+    pads = [_pad_rows(x, n_max) for x in xs]
+    outs = [torch.empty((x.shape[0], world * n_max) + tuple(x.shape[2:]), dtype=x.dtype, device=x.device) for x in xs]
+    pairs = [(o[b], xp[b]) for o, xp in zip(outs, pads) for b in range(xp.shape[0])]
+    want = (_COALESCE["ok"] is not False and len(pairs) > 1 and pads[0].is_cuda and dist.get_backend(group) == "nccl"
+            and os.environ.get("LCV_SP_COALESCE", "1") == "1")
+    done = False
+    if want:
+        try:
+            with dist._coalescing_manager(group=group, device=pads[0].device, async_ops=False):
+                for o, i in pairs:
+                    dist.all_gather_into_tensor(o, i, group=group)
+            _COALESCE["ok"] = done = True
+        except (RuntimeError, AttributeError, TypeError) as ex:   # an older / different backend: fall back for good, say so once
+            if _COALESCE["ok"] is None:
+                print(f"  sequence parallel: grouped K/V gather unavailable ({type(ex).__name__}: {ex}); using one collective per tensor")
+            _COALESCE["ok"] = False
+    if not done:
+        for o, i in pairs:
+            dist.all_gather_into_tensor(o, i, group=group)
+    return [o[:, :N] for o in outs]
+
+
+def _gather_rows(x: torch.Tensor, counts: List[int], S: int, group=None, out: torch.Tensor = None) -> torch.Tensor:
+    """All-gather ONE tensor along the token axis; returns [B, N, ...] in sequence order."""
+    return _gather_many([x], counts, S, group)[0]
 
 
 def all_gather_kv(k_local: torch.Tensor, v_local: torch.Tensor, counts: List[int], tokens_per_frame: int,
                   group=None) -> Tuple[torch.Tensor, torch.Tensor]:
-    """[B, n_local, H, D] shards -> full [B, N, H, D] K and V in frame order."""
-    return (_gather_rows(k_local, counts, tokens_per_frame, group),
-            _gather_rows(v_local, counts, tokens_per_frame, group))
+    """[B, n_local, H, D] shards -> full [B, N, H, D] K and V in sequence order (one grouped launch on RCCL)."""
+    k, v = _gather_many([k_local, v_local], counts, tokens_per_frame, group)
+    return k, v
 
 
 def reduce_scatter_kv_grad(d_full: torch.Tensor, counts: List[int], tokens_per_frame: int, group=None) -> torch.Tensor:
@@ -105,23 +148,41 @@ def reduce_scatter_kv_grad(d_full: torch.Tensor, counts: List[int], tokens_per_f
 
 
 class SPContext:
-    """Frame-axis shard of one forward pass: which latent frames / tokens this rank owns and the K/V exchange.
+    """Token-row shard of one forward pass: which rows / tokens of the sequence this rank owns and the K/V exchange.
 
+    `SPContext(num_frames, tokens_per_frame, group, rows_per_frame=h/2)`: the sequence is `num_frames * rows_per_frame` units of
+    `tokens_per_frame / rows_per_frame` tokens; `rows_per_frame = 1` (the default) shards whole frames as rounds 1-2 did.
     `group` is a torch.distributed process group ("nccl" = RCCL over xGMI in production).  With the gloo backend
     (CPU tests, or several ranks sharing one GPU) device tensors are staged through host memory for the collective."""
 
-    def __init__(self, num_frames: int, tokens_per_frame: int, group=None):
+    def __init__(self, num_frames: int, tokens_per_frame: int, group=None, rows_per_frame: int = 1):
         import torch.distributed as dist
+        if tokens_per_frame % rows_per_frame:
+            raise ValueError("tokens_per_frame must be a multiple of rows_per_frame")
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
-        self.S = tokens_per_frame
-        self.counts = frame_shards(num_frames, self.world)
-        self.t0 = sum(self.counts[: self.rank])
-        self.t1 = self.t0 + self.counts[self.rank]
         self.num_frames = num_frames
+        self.rows_per_frame = rows_per_frame
+        self.tokens_per_frame = tokens_per_frame
+        self.S = tokens_per_frame // rows_per_frame              # tokens per shard unit
+        self.num_units = num_frames * rows_per_frame
+        self.counts = frame_shards(self.num_units, self.world)
+        self.t0 = sum(self.counts[: self.rank])                  # first unit (token row, or frame) of this rank
+        self.t1 = self.t0 + self.counts[self.rank]
+        self.num_cond_frames = 0                                 # conditioning frames pinned in the sequence (set by the model)
         self._host_staged = dist.get_backend(group) == "gloo"
         self.overlap = os.environ.get("LCV_SP_OVERLAP", "0") == "1"
+
+    @property
+    def grid(self):
+        """(T, h/2, w/2) of the whole clip: RoPE tables are built for it and addressed by the global token offset."""
+        return (self.num_frames, self.rows_per_frame, self.S)
+
+    def local_units_of_leading_frames(self, n_frames: int) -> int:
+        """How many of this rank's units belong to the first `n_frames` frames (the pinned conditioning frames: always a
+        prefix of the shard)."""
+        return max(0, min(self.t1, int(n_frames) * self.rows_per_frame) - self.t0)
 
     _SIDE = {}
 
@@ -149,8 +210,10 @@ class SPContext:
         return fn(x)
 
     def all_gather_kv(self, k_local: torch.Tensor, v_local: torch.Tensor):
-        k = self._coll(lambda t: _gather_rows(t, self.counts, self.S, self.group), k_local)
-        v = self._coll(lambda t: _gather_rows(t, self.counts, self.S, self.group), v_local)
+        if self._host_staged and k_local.is_cuda:
+            k, v = _gather_many([k_local.cpu(), v_local.cpu()], self.counts, self.S, self.group)
+            return k.to(k_local.device), v.to(v_local.device)
+        k, v = _gather_many([k_local, v_local], self.counts, self.S, self.group)
         return k, v
 
     def padded_zeros(self, like: torch.Tensor) -> torch.Tensor:
@@ -183,11 +246,11 @@ class SPContext:
                 p_.grad = r.to(g.dtype)
 
     def gather_frames(self, x_local: torch.Tensor) -> torch.Tensor:
-        """[B, C, T_local, H, W] -> [B, C, T, H, W] on every rank."""
+        """[B, C, U_local, H, W] -> [B, C, U, H, W] on every rank (U = shard units: token rows of height 2, or frames)."""
         B, C, Tl, H, W = x_local.shape
         rows = x_local.permute(0, 2, 1, 3, 4).reshape(B, Tl, C * H * W).contiguous()
         full = self._coll(lambda t: _gather_rows(t, self.counts, 1, self.group), rows)
-        return full.view(B, self.num_frames, C, H, W).permute(0, 2, 1, 3, 4).contiguous()
+        return full.view(B, self.num_units, C, H, W).permute(0, 2, 1, 3, 4).contiguous()
 
 
 class _GatherFramesFn(torch.autograd.Function):

@@ -87,6 +87,23 @@ def _worker(rank, world, port, tmp):
         dg += float(rank + 1)
         dl = ctx.reduce_scatter_kv(dg)
         assert dl.shape == (2, counts[rank] * S, H, D) and torch.all(dl == 3.0)
+        # round 3: the shard unit is a TOKEN ROW.  5 frames x 3 rows of 2 tokens = 15 rows -> 8 + 7 (frames would give 3 + 2):
+        # shards end inside a frame, conditioning frames pinned in the sequence split over the ranks by rows
+        rctx = sp.SPContext(T, S, rows_per_frame=3)
+        assert rctx.counts == [8, 7] and rctx.S == 2 and rctx.grid == (5, 3, 2) and rctx.num_units == 15
+        assert rctx.token_offset == (0 if rank == 0 else 16) and sp.pads_at_end(rctx.counts)
+        assert rctx.local_units_of_leading_frames(2) == (6 if rank == 0 else 0)      # 2 cond frames = rows 0..5: all on rank 0
+        assert rctx.local_units_of_leading_frames(3) == (8 if rank == 0 else 1)      # rows 0..8: 8 on rank 0, 1 on rank 1
+        lo_r, hi_r = rctx.token_offset, rctx.token_offset + rctx.counts[rank] * rctx.S
+        kg, vg = rctx.all_gather_kv(k2[:, lo_r:hi_r].contiguous(), (k2 * 3.0)[:, lo_r:hi_r].contiguous())
+        assert torch.equal(kg, k2) and torch.equal(vg, k2 * 3.0) and kg._base.shape[1] == 2 * 8 * 2   # one padded buffer per tensor
+        dgr = rctx.padded_zeros(kg); dgr += float(rank + 1)
+        dlr = rctx.reduce_scatter_kv(dgr)
+        assert dlr.shape == (2, rctx.counts[rank] * 2, H, D) and torch.all(dlr == 3.0)
+        # the prediction comes back by rows of height 2: [B, C, rows_local, 2, W] -> [B, C, 15, 2, W]
+        pred = torch.arange(15 * 2 * 4, dtype=torch.float32).view(1, 1, 15, 2, 4)
+        got = rctx.gather_frames(pred[:, :, rctx.t0:rctx.t1].contiguous())
+        assert torch.equal(got, pred)
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -102,6 +119,26 @@ def test_frame_shards_put_the_pads_at_the_end_when_they_can():
         for W in (1, 2, 3, 4, 8):
             c = sp.frame_shards(T, W)
             assert sum(c) == T and len(c) == W and all(x >= 0 for x in c) and c == sorted(c, reverse=True)
+
+
+def test_token_row_shards_balance_the_headline_shapes():
+    """Round 3: whole latent frames cannot balance 49x720p on 8 ranks (13 frames -> 2,2,2,2,2,1,1,1: 0.81, and
+    gaps inside the padded sequence); token rows can, and always keep the pads at the end (the single-collective path)."""
+    sys.path.insert(0, str(ROOT / "longcat-video-tta_amd"))
+    from longcat_video.parallel import sequence_parallel as sp
+    cases = {"K3 49x720p": (13, 45, 80), "K5 121x480p": (31, 30, 52), "K2 49x480p": (13, 30, 52), "K3' 49x90x160": (49, 45, 80)}
+    for name, (T, rows, per_row) in cases.items():
+        for W in (2, 4, 8):
+            c = sp.row_shards(T * rows, W)
+            assert sum(c) == T * rows and sp.pads_at_end(c), (name, W, c)
+            tokens = [x * per_row for x in c]
+            eff = sum(tokens) / (W * max(tokens))
+            assert eff > 0.98, (name, W, c, eff)
+            assert max(tokens) - min(tokens) <= (W - 1) * per_row           # at most W - 1 rows of imbalance, all on the last rank
+    c = sp.row_shards(13 * 45, 8)
+    assert c == [74] * 7 + [67] and [x * 80 for x in c] == [5920] * 7 + [5360]      # K3 on 8 ranks: 5 850 +- 80 tokens is the ceiling share
+    f = sp.frame_shards(13, 8)
+    assert sum(f) / (8 * max(f)) < 0.82 and not sp.pads_at_end(f)                   # what rounds 1-2 did
 
 
 def test_world_size_2_gloo():

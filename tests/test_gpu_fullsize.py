@@ -301,7 +301,8 @@ def test_gemm_w2_k3p_cfg_batch_rows_past_4gb_vs_fp32(monkeypatch):
     c = ops.gemm_nt(a, w, b)
     line = 2 ** 32 // (2 * K)                                          # first row whose bytes cross 4 GiB
     rows = torch.cat([torch.randint(0, M, (64,), generator=g, device=DEV),
-                      torch.tensor([0, 255, 256, line - 1, line, line + 1, 2 * line + 7, M - 257, M - 96, M - 1], device=DEV)])
+                      torch.tensor([0, 255, 256, line - 1, line, line + 1, line + 77777, M - 257, M - 96, M - 1], device=DEV)])
+    assert int(rows.max()) < M and int(rows.min()) >= 0          # (torch's gather does not check: an index past M is a GPU fault)
     ref = a[rows].float() @ w.float().t() + b.float()
     assert rel_l2(c[rows], ref) < 2e-3
     worst = ((c[rows].float() - ref).norm(dim=1) / ref.norm(dim=1)).max().item()

@@ -1,5 +1,7 @@
-"""GPU: frame-axis sequence-parallel DiT forward with 2 ranks (both on this box's one GPU, gloo process group with
-host-staged K/V exchange) equals the single-process forward.  Uneven shards (5 frames -> 3 + 2), global RoPE offsets."""
+"""GPU: sequence-parallel DiT forward with 2 ranks (both on this box's one GPU, gloo process group with host-staged K/V
+exchange) equals the single-process forward.  Round 3: the shard unit is a token row, so the 5-frame clip (grid 5 x 4 x 6 =
+20 rows of 6 tokens) splits 10 + 10 rows = 2.5 frames each - shards end INSIDE a frame -, global RoPE offsets, a CFG batch of
+two through the same collectives."""
 import os
 import sys
 from pathlib import Path
@@ -53,8 +55,19 @@ def _worker(rank, world, port, out_path):
             got2 = m(noise, ts[:, 2:].contiguous(), y, mask.cuda(), num_cond_latents=2, kv_cache_dict=kv_sp)
             m.disable_sequence_parallel()
         err2 = (torch.linalg.vector_norm(got2 - ref2) / torch.linalg.vector_norm(ref2)).item()
+        # a CFG pair (B = 2, different prompts / masks) on an odd row count: 3 frames x 5 rows = 15 rows -> 8 + 7
+        with torch.no_grad():
+            hs3 = torch.randn(2, 16, 3, 10, 12, generator=g).to(BF16).cuda()
+            y3 = torch.randn(2, 1, 16, 64, generator=g).to(BF16).cuda()
+            mask3 = torch.zeros(2, 16, dtype=torch.int64); mask3[0, :10] = 1; mask3[1, :4] = 1
+            ts3 = torch.tensor([[0.0, 640.0, 640.0]] * 2).to(BF16).cuda()
+            ref3 = m(hs3, ts3, y3, mask3.cuda(), num_cond_latents=1)
+            m.enable_sequence_parallel(None)
+            got3 = m(hs3, ts3, y3, mask3.cuda(), num_cond_latents=1)       # the conditioning frame pinned: rows 0..4 of rank 0's 8
+            m.disable_sequence_parallel()
+        err3 = (torch.linalg.vector_norm(got3 - ref3) / torch.linalg.vector_norm(ref3)).item()
         if rank == 0:
-            Path(out_path).write_text(f"{err} {err2} {err_ov}")
+            Path(out_path).write_text(f"{err} {err2} {err_ov} {err3}")
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -63,10 +76,11 @@ def _worker(rank, world, port, out_path):
 def test_sequence_parallel_forward_matches_single_gpu(tmp_path):
     out = tmp_path / "err.txt"
     mp.spawn(_worker, args=(2, 29700 + os.getpid() % 200, str(out)), nprocs=2, join=True)
-    err, err2, err_ov = (float(x) for x in out.read_text().split())
-    print("SP vs single rel-L2:", err, "; with the conditioning-frame KV cache:", err2, "; overlapped gather + LSE merge:", err_ov)
+    err, err2, err_ov, err3 = (float(x) for x in out.read_text().split())
+    print("SP vs single rel-L2:", err, "; with the conditioning-frame KV cache:", err2, "; overlapped gather + LSE merge:", err_ov,
+          "; CFG pair with a pinned conditioning frame, 8 + 7 rows:", err3)
     # identical kernels on identical rows; only the attention's K/V tile boundaries can differ -> fp32-order noise
-    assert err < 2e-3 and err2 < 2e-3
+    assert err < 2e-3 and err2 < 2e-3 and err3 < 2e-3
     # the overlapped form partitions the softmax over key ranges and merges in fp32: same function, one more bf16 rounding
     assert err_ov < 5e-3
 
