@@ -53,11 +53,20 @@ __device__ __forceinline__ unsigned x_pack(float lo, float hi) { unsigned y; asm
 // with more than 256 registers into AGPRs - the score tiles too, which then cost a v_accvgpr_read per element before the
 // exponentials.  Score tiles live in arch VGPRs ("v"), dK / dV accumulators in AGPRs ("a").
 // (asm is opaque to the hazard recogniser: every result below is read >= 3 MFMA slots after the MFMA that wrote it.)
-__device__ __forceinline__ void mfma_v(f32x16& c, const bf16x8& a, const bf16x8& b) {
-  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+// the same with the B operand in AGPRs: the K / V rows of the wave's keys are loaded once and only ever read by MFMAs, so they
+// sit in the half of the register file the vector instructions cannot address (64 arch VGPRs back for the second score set)
+// GUARD: outside the straight-line steady loop hipcc re-homes accumulators and operands between code paths with v_accvgpr_mov /
+// v_mov copies placed DIRECTLY in front of the asm that reads them; the recogniser cannot see the MFMA inside, so the wait states
+// of "VALU write -> MFMA read" are spelled out (4 of them; measured symptom without: dK of small shapes wrong and not repeatable)
+template <bool GUARD = true>
+__device__ __forceinline__ void mfma_vb(f32x16& c, const bf16x8& a, const bf16x8& b) {
+  if constexpr (GUARD) asm volatile("s_nop 3\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "a"(b));
+  else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "a"(b));
 }
+template <bool GUARD = true>
 __device__ __forceinline__ void mfma_a(f32x16& c, const bf16x8& a, const bf16x8& b) {
-  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+  if constexpr (GUARD) asm volatile("s_nop 3\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+  else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
 }
 
 // Diagnostic build only (scratch/attn_lab/build_dkv3.sh defines LCV_DKV3_STAMPS; the product never does): s_memtime stamps of
@@ -71,7 +80,7 @@ __device__ int g_dkv3_dbg_block = 0;
     __builtin_amdgcn_sched_barrier(0);                                                                      \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                              \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
-    if (lane_now() == 0) *reinterpret_cast<AS3X unsigned long long*>(lds + 6 * STAGE + wave * 1024 + (((it) - 100) * 8 + (id)) * 8) = t_; \
+    if (lane_now() == 0) *reinterpret_cast<AS3X unsigned long long*>(lds + 7 * STAGE + wave * 1024 + (((it) - 100) * 8 + (id)) * 8) = t_; \
   }
 extern "C" void attn_dkv3_set_stamps(unsigned long long* buf, int block) {
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dkv3_dbg), &buf, sizeof(buf));
@@ -92,7 +101,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   constexpr int TILE_BYTES = QT * 256;                  // one [32][128] bf16 tile
   constexpr int STAGE = 2 * TILE_BYTES + 2 * QT * 4;    // Q | dO | -lse (log2 units) | -delta
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int NST = 6;
+  constexpr int NST = 7;
   lds_u8x* lds = (lds_u8x*)smem;                        // [NST] stages
 
   const int tid = threadIdx.x;
@@ -115,6 +124,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       kf[ks] = *reinterpret_cast<const bf16x8*>(kp + 16 * ks);
       vf[ks] = *reinterpret_cast<const bf16x8*>(vp + 16 * ks);
     }
+    // into AGPRs HERE, long before the first MFMA that reads them: left to hipcc, the v_accvgpr_write copies land right in front
+    // of the first asm MFMA, which (opaque to the hazard recogniser) then reads them without the required wait states
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+a"(kf[ks]), "+a"(vf[ks]));
   }
 
   // ---- Q / dO tile staging by asm-issued LDS-DMA (2 + 2 pieces per wave), the row constants by one dword piece (wave 0) ----
@@ -183,30 +196,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int e = 0; e < 16; ++e) { dkacc[d][e] = 0.f; dvacc[d][e] = 0.f; }
 
   const int nt = (int)((p.Nq + QT - 1) / QT);
-  // ---- prologue: tiles 0 .. 4 requested; everything landed before the first read ----
+  // ---- prologue: tiles 0 .. 5 requested; everything landed before the first read ----
 #pragma unroll
-  for (int i = 0; i < 5; ++i)
+  for (int i = 0; i < 6; ++i)
     if (i < nt) load_tile((int64_t)i * QT, i * STAGE);
   lcv_dma_wait_all();
   __syncthreads();
 
-  f32x16 s, dp;                                          // S / dP of the tile whose vector work comes next
-  // fragment rings: an LDS read returns well over two MFMA slots after its issue, and a step of either phase is only two MFMAs,
-  // so fragments are requested PD steps ahead (ring of PD + 1)
+  // two score sets: while the vector work of tile i reads one, the S / dP chains of tile i + 1 accumulate into the other
+  f32x16 sA, dA, sB, dB;
+  // fragment rings: an LDS read returns well over two MFMA slots after its issue, so fragments are requested PD steps ahead
   constexpr int PD = 2, RING = PD + 1;
-  bf16x8 aq[RING], ad[RING];                             // row fragments of phase X
-  s16x4 dlo[RING], dhi[RING], qlo[RING], qhi[RING];      // transposed fragments of phase Y
+  bf16x8 aq[RING], ad[RING];                             // row fragments (S / dP chains)
+  s16x4 dlo[RING], dhi[RING], qlo[RING], qhi[RING];      // transposed fragments (dV / dK products)
 
-  // requests: the row constants of the tile in stage `sx` into the score tuples (their initial accumulators: element e <-> query
+  // requests: the row constants of the tile in stage `sx` into a score set (the initial accumulators: element e <-> query
   // (e & 3) + 8 (e >> 2) + 4 h), its row fragments of k-step ks, the transposed fragments of group g = 4 ss + d of the tile in `sy`
-  auto ld_consts = [&](int sx) {
+  auto ld_consts = [&](int sx, f32x16& S, f32x16& D) {
     const lds_u8x* lb = lds + sx + 2 * TILE_BYTES;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const f32x4 l4 = *reinterpret_cast<const AS3X f32x4*>(lb + (8 * g + 4 * h) * 4);
       const f32x4 d4 = *reinterpret_cast<const AS3X f32x4*>(lb + QT * 4 + (8 * g + 4 * h) * 4);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { s[4 * g + e] = l4[e]; dp[4 * g + e] = d4[e]; }
+      for (int e = 0; e < 4; ++e) { S[4 * g + e] = l4[e]; D[4 * g + e] = d4[e]; }
     }
   };
   auto ld_x = [&](int sx, int ks, int st) {
@@ -225,11 +238,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // exponential of element i, the product of element i - 1 and the packs of the pairs that have just completed; results go to
   // short-lived scalars, never back into the score tuples.  18 steps (0 .. 17) per tile.
   float pe[16], de[16];
-  auto valu_step = [&](int i, PackedTile& out) {
-    if (i < 16) pe[i] = x_exp2(s[i]);
+  auto valu_step = [&](int i, PackedTile& out, const f32x16& S, const f32x16& D) {
+    if (i < 16) pe[i] = x_exp2(S[i]);
     if (i >= 1 && i <= 16) {
       const int j = i - 1;
-      de[j] = x_mul(pe[j], dp[j]);
+      de[j] = x_mul(pe[j], D[j]);
       if (j & 1) out.p[j >> 3][(j & 7) >> 1] = x_pack(pe[j - 1], pe[j]);
     }
     if (i >= 2 && i <= 17) {
@@ -237,130 +250,190 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       if (j & 1) out.ds[j >> 3][(j & 7) >> 1] = x_pack(de[j - 1], de[j]);
     }
   };
+  auto mfma_y = [&](int g, int m, const PackedTile& cur, auto guard_c) {   // product m (0: dV, 1: dK) of group g = 4 ss + d
+    constexpr bool GUARD = decltype(guard_c)::value;
+    const int ss = g >> 2, d = g & 3, st = g % RING;
+    if (m) {
+      const bf16x8 qtf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(qlo[st], qhi[st], 0, 1, 2, 3, 4, 5, 6, 7));
+      const u32x4 wd = {cur.ds[ss][0], cur.ds[ss][1], cur.ds[ss][2], cur.ds[ss][3]};
+      mfma_a<GUARD>(dkacc[d], qtf, __builtin_bit_cast(bf16x8, wd));
+    } else {
+      const bf16x8 dof = __builtin_bit_cast(bf16x8, __builtin_shufflevector(dlo[st], dhi[st], 0, 1, 2, 3, 4, 5, 6, 7));
+      const u32x4 wp = {cur.p[ss][0], cur.p[ss][1], cur.p[ss][2], cur.p[ss][3]};
+      mfma_a<GUARD>(dvacc[d], dof, __builtin_bit_cast(bf16x8, wp));
+    }
+  };
 
-  // phase X: S = Q K^T - lse, dP = dO V^T - delta of the tile in stage `sx`; the constants and k-step 0 were requested by the caller.
-  // `sy_next >= 0`: the first transposed fragments of the NEXT phase Y (tile in stage sy_next) are requested in the last gap.
-  auto phase_x = [&](int sx, int sy_next) {
+  // plain phases (pipeline prologue and the last tile): S / dP of the tile in stage `sx` into (S, D), constants and the first PD
+  // k-steps requested by the caller; products of the tile in stage `sy` with the packs `cur`, first PD groups requested by the caller
+  auto phase_x = [&](int sx, f32x16& S, f32x16& D) {
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
       if (ks + PD < 8) ld_x(sx, ks + PD, (ks + PD) % RING);
-      else if (sy_next >= 0) ld_y(sy_next, ks + PD - 8, (ks + PD - 8) % RING);   // the first PD groups of the next phase Y
-      const int st = ks % RING;
-      mfma_v(s, aq[st], kf[ks]);
+      mfma_vb(S, aq[ks % RING], kf[ks]);
       SCHED_FENCE();
-      mfma_v(dp, ad[st], vf[ks]);
+      mfma_vb(D, ad[ks % RING], vf[ks]);
       SCHED_FENCE();
     }
   };
-  // phase Y: dV^T += dO^T P, dK^T += Q^T dS' of the tile in stage `sy` with its packs `cur` (group 0 was requested by the caller).
-  // VALU: the vector work of the tile whose S / dP sit in (s, dp) runs in the gaps (finished by gap 11) and leaves its packs in `nxt`.
-  // `dma_q0 >= 0`: the five LDS-DMA pieces of the tile at query dma_q0 go out in gaps 0 .. 4, into stage `dma_stage`.
-  // `sx_next >= 0`: the constants and the first row fragments of the NEXT phase X are requested in the last gaps.
-  auto phase_y = [&](int sy, const PackedTile& cur, PackedTile& nxt, auto valu_c, int64_t dma_q0, int dma_stage, int sx_next,
-                     auto steady_c) {
-    constexpr bool VALU = decltype(valu_c)::value;
-    constexpr bool STEADY = decltype(steady_c)::value;     // a full tile is requested and a phase X follows: no edge conditions
+  auto phase_y = [&](int sy, const PackedTile& cur) {
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
       if (g + PD < 8) ld_y(sy, g + PD, (g + PD) % RING);
-      const int ss = g >> 2, d = g & 3, st = g % RING;
-      const bf16x8 dof = __builtin_bit_cast(bf16x8, __builtin_shufflevector(dlo[st], dhi[st], 0, 1, 2, 3, 4, 5, 6, 7));
-      const bf16x8 qtf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(qlo[st], qhi[st], 0, 1, 2, 3, 4, 5, 6, 7));
-      const u32x4 wp = {cur.p[ss][0], cur.p[ss][1], cur.p[ss][2], cur.p[ss][3]};
-      const u32x4 wd = {cur.ds[ss][0], cur.ds[ss][1], cur.ds[ss][2], cur.ds[ss][3]};
+      mfma_y(g, 0, cur, std::true_type{});
+      SCHED_FENCE();
+      mfma_y(g, 1, cur, std::true_type{});
+      SCHED_FENCE();
+    }
+    // the two tails (odd / even tile count) end with the accumulators in different registers and hipcc copies one set over -
+    // v_accvgpr_mov straight behind the last (opaque) MFMAs read results that are not back yet: d-blocks of dK came out without
+    // their last group.  The copies now sit behind this statement's wait states.
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15"
+                 : "+a"(dkacc[0]), "+a"(dkacc[1]), "+a"(dkacc[2]), "+a"(dkacc[3]), "+a"(dvacc[0]), "+a"(dvacc[1]), "+a"(dvacc[2]), "+a"(dvacc[3]));
+  };
+
+  // stage byte offsets of tiles i - 1, i, i + 1, i + 2 and i + 5 at the top of iteration i: tile t lives in stage t % NST
+  int s_m1 = 0, s_0 = STAGE, s_p1 = 2 * STAGE, s_p2 = 3 * STAGE, s_p5 = 6 * STAGE;
+  auto adv = [&](int x) { return x + STAGE == NST * STAGE ? 0 : x + STAGE; };
+
+  // ONE merged phase per tile: the MFMAs alternate between the S / dP chains of tile i + 1 and the products of tile i - 1,
+  //     S(ks = g)   dV(g)   dP(ks = g)   dK(g)        g = 0 .. 7,
+  // so a chain's next link is four MFMA slots away (with one wave per SIMD and two chains back to back, a link waited for its
+  // predecessor: 47 cycles per MFMA measured) and the 54 vector instructions of tile i, the 5 LDS-DMA requests of tile i + 5 and
+  // the fragment reads spread over 32 gaps.  Preconditions (left by the previous iteration): (AS, AD) hold the row constants of tile
+  // i + 1, k-steps 0 .. PD - 1 of tile i + 1 and groups 0 .. PD - 1 of tile i - 1 are requested.  (RS, RD) = S / dP of tile i.
+  auto merged = [&](int i, const PackedTile& cur, PackedTile& nxt, f32x16& RS, f32x16& RD, f32x16& AS, f32x16& AD, auto steady_c) {
+    constexpr bool STEADY = decltype(steady_c)::value;     // tiles up to i + 5 exist and are full: straight-line code
+    const bool has_x = STEADY || i + 1 < nt;               // tile i + 1 exists: its chains run
+    const bool has_x2 = STEADY || i + 2 < nt;              // tile i + 2 exists: its constants / first fragments are requested at the end
+    const bool has_dma = STEADY || i + 5 < nt;
+    DKV3_STAMP(i, 0)
+    // the last tile's iteration has no S / dP MFMAs in front of its vector work: the dP chain of tile i ended two MFMA slots ago
+    // and its results are not back yet (symptom: dK of the last tile wrong, the same wrong every run).  Once per workgroup.
+    if constexpr (!STEADY)
+      if (!has_x) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
 #pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        if (m) mfma_a(dkacc[d], qtf, __builtin_bit_cast(bf16x8, wd));
-        else mfma_a(dvacc[d], dof, __builtin_bit_cast(bf16x8, wp));
+    for (int g = 0; g < 8; ++g) {
+      if (g + PD < 8) {
+#ifndef LCV_DKV3_NO_ROW
+        if (has_x) ld_x(s_p1, g + PD, (g + PD) % RING);
+#endif
+#ifndef LCV_DKV3_NO_TR
+        ld_y(s_m1, g + PD, (g + PD) % RING);
+#endif
+      }
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        // unguarded only where the code is straight-line and the copies (if any) sit at the top of the iteration: g >= 1 of STEADY
+        if (g >= 1 && STEADY) {
+          if (m == 0) mfma_vb<false>(AS, aq[g % RING], kf[g]);
+          else if (m == 2) mfma_vb<false>(AD, ad[g % RING], vf[g]);
+          else mfma_y(g, m >> 1, cur, std::false_type{});
+        } else {
+          if (m == 0) { if (has_x) mfma_vb<true>(AS, aq[g % RING], kf[g]); }
+          else if (m == 2) { if (has_x) mfma_vb<true>(AD, ad[g % RING], vf[g]); }
+          else mfma_y(g, m >> 1, cur, std::true_type{});
+        }
         SCHED_FENCE();
-        const int gap = 2 * g + m;                        // 0 .. 15
-        if constexpr (VALU) {
-          // 18 steps over gaps 0 .. 13: two steps in gaps 0 .. 3, one in gaps 4 .. 13 (the score tuples are free from gap 14 on)
-          if (gap < 4) { valu_step(2 * gap, nxt); valu_step(2 * gap + 1, nxt); }
-          else if (gap < 14) valu_step(gap + 4, nxt);
+        const int gap = 4 * g + m;                        // 0 .. 31
+        // 18 vector steps at gaps 0, 1, 3, 4, 6, 7, 9, 10, 12, 14, 15, 17, 18, 20, 21, 23, 24, 26 (= floor(28 j / 18))
+#pragma unroll
+        for (int j = 0; j < 18; ++j)
+#ifndef LCV_DKV3_NO_VALU
+          if ((28 * j) / 18 == gap) valu_step(j, nxt, RS, RD);
+#else
+          if ((28 * j) / 18 == gap && j == 0) valu_step(j, nxt, RS, RD);
+#endif
+        // the five LDS-DMA requests of tile i + 5 in gaps that carry no vector step
+#ifdef LCV_DKV3_NO_DMA
+        if (false) {
+#else
+        if (has_dma) {
+#endif
+          if (gap == 2) load_piece(0, (int64_t)(i + 5) * QT, s_p5, STEADY);
+          if (gap == 5) load_piece(1, (int64_t)(i + 5) * QT, s_p5, STEADY);
+          if (gap == 8) load_piece(2, (int64_t)(i + 5) * QT, s_p5, STEADY);
+          if (gap == 11) load_piece(3, (int64_t)(i + 5) * QT, s_p5, STEADY);
+          if (gap == 13) load_piece(4, (int64_t)(i + 5) * QT, s_p5, STEADY);
         }
-        if ((STEADY || dma_q0 >= 0) && gap >= 5 && gap < 10) load_piece(gap - 5, dma_q0, dma_stage, STEADY);
-        if (STEADY || sx_next >= 0) {
-          if (gap == 14) { ld_consts(sx_next); ld_x(sx_next, 0, 0); }
-          if (gap == 15) ld_x(sx_next, 1, 1);              // (PD = 2: the first two k-steps of the next phase X)
-        }
+        // what the next iteration expects: the row constants of tile i + 2 (into the set the vector work has just left: its last
+        // read was in gap 26), its first k-steps, and the first groups of tile i (all landed before the previous barrier)
+#if !defined(LCV_DKV3_NO_ROW) && !defined(LCV_DKV3_NO_TR)
+        if (gap == 28 && has_x2) ld_consts(s_p2, RS, RD);
+        if (gap == 29) { if (has_x2) ld_x(s_p2, 0, 0); ld_y(s_0, 0, 0); }
+        if (gap == 31) { if (has_x2) ld_x(s_p2, 1, 1); ld_y(s_0, 1, 1); }
+#endif
         SCHED_FENCE();
       }
     }
+    DKV3_STAMP(i, 1)
+    // outside the steady loop the paths that join behind this iteration keep the score sets in different registers, and hipcc's
+    // copies would read the chains' last results right behind the (opaque) MFMAs: rows 16 .. 31 of the last tile came out one
+    // k-step short.  Routing the sets through this statement puts the copies behind 2 x 16 wait states.
+    if constexpr (!STEADY) asm volatile("s_nop 15\n\ts_nop 15" : "+v"(AS), "+v"(AD));
+    // requests are retired in order: tile i + 3 must have landed, the 5 + 5 of tiles i + 4 and i + 5 may stay in flight (towards
+    // the end of the sweep fewer were made)
+#ifndef LCV_DKV3_NO_DMA
+    if (STEADY || i + 5 < nt) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if (i + 4 < nt) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else lcv_dma_wait_all();
+#endif
+    DKV3_STAMP(i, 2)
+    __builtin_amdgcn_s_barrier();
+    DKV3_STAMP(i, 3)
+    s_m1 = s_0; s_0 = s_p1; s_p1 = s_p2; s_p2 = adv(s_p2); s_p5 = adv(s_p5);
+    DKV3_STAMP(i, 4)
   };
 
   PackedTile pa, pb;
-  // ---- pipeline prologue: X(0), the vector work of tile 0 in the open, X(1) ----
-  ld_consts(0);
+  // ---- pipeline prologue: S / dP of tile 0 -> set A, its vector work in the open -> pa, S / dP of tile 1 -> set B ----
+  ld_consts(0, sA, dA);
 #pragma unroll
   for (int i = 0; i < PD; ++i) ld_x(0, i, i);
-  phase_x(0, -1);
+  phase_x(0, sA, dA);
+  // (the only place where vector instructions read MFMA results right behind the MFMAs: asm is opaque to the hazard recogniser,
+  // so the wait states are spelled out - 8 x 16 cycles, once per workgroup)
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
 #pragma unroll
-  for (int i = 0; i < 18; ++i) valu_step(i, pa);
+  for (int i = 0; i < 18; ++i) valu_step(i, pa, sA, dA);
   if (nt > 1) {
-    ld_consts(STAGE);
+    ld_consts(STAGE, sB, dB);
 #pragma unroll
     for (int i = 0; i < PD; ++i) ld_x(STAGE, i, i);
-    phase_x(STAGE, 0);                                    // + the first transposed fragments of tile 0
-  } else {
-#pragma unroll
-    for (int i = 0; i < PD; ++i) ld_y(0, i, i);
+    phase_x(STAGE, sB, dB);
   }
-  // stage byte offsets of tiles i - 1, i, i + 1 and i + 4 at the top of iteration i: tile t lives in stage t % NST
-  int sa = 0, sb_ = STAGE, sc = 2 * STAGE, sd = 5 * STAGE;
-  auto adv = [&](int x) { return x + STAGE == NST * STAGE ? 0 : x + STAGE; };
-  // iteration i: products of tile i - 1 (cur) || vector work of tile i (-> nxt) || request of tile i + 4 (into the stage tile i - 2
-  // left before the previous barrier); S / dP of tile i + 1; tile i + 2 has landed (the two newer ones may still fly); barrier
-  auto iteration = [&](int i, const PackedTile& cur, PackedTile& nxt, auto steady_c) {
-    constexpr bool STEADY = decltype(steady_c)::value;     // tile i + 4 exists and is full: straight-line code, no edge conditions
-    if constexpr (STEADY) {
-      DKV3_STAMP(i, 0)
-      phase_y(sa, cur, nxt, std::true_type{}, (int64_t)(i + 4) * QT, sd, sc, std::true_type{});
-      DKV3_STAMP(i, 1)
-      phase_x(sc, sb_);                                   // + the first transposed fragments of tile i (next iteration's phase Y)
-      DKV3_STAMP(i, 2)
-      // requests are retired in order: the 5 + 5 of tiles i + 3 and i + 4 may stay outstanding behind tile i + 2
-      asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-      DKV3_STAMP(i, 3)
-    } else {
-      const bool has_x = i + 1 < nt;
-      phase_y(sa, cur, nxt, std::true_type{}, (i + 4 < nt) ? (int64_t)(i + 4) * QT : -1, sd, has_x ? sc : -1, std::false_type{});
-      if (has_x) phase_x(sc, sb_);
-      else {
+  // what iteration 1 expects: constants and first k-steps of tile 2 (-> set A), first groups of tile 0
+  if (nt > 2) {
+    ld_consts(2 * STAGE, sA, dA);
 #pragma unroll
-        for (int g = 0; g < PD; ++g) ld_y(sb_, g, g);
-      }
-      if (i + 4 < nt) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");   // (towards the end fewer requests were made)
-      else if (i + 3 < nt) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-      else lcv_dma_wait_all();
-    }
-    __builtin_amdgcn_s_barrier();
-    if constexpr (STEADY) { DKV3_STAMP(i, 4) }
-    sa = sb_; sb_ = sc; sc = adv(sc); sd = adv(sd);
-  };
+    for (int i = 0; i < PD; ++i) ld_x(2 * STAGE, i, i);
+  }
+#pragma unroll
+  for (int g = 0; g < PD; ++g) ld_y(0, g, g);
   {
     const int nfull = (int)(p.Nq / QT);                    // tiles 0 .. nfull - 1 are full
     int i = 1;
-    for (; i + 5 < nfull; i += 2) {                       // steady state: tiles i + 4 and i + 5 exist and are full
-      iteration(i, pa, pb, std::true_type{});
-      iteration(i + 1, pb, pa, std::true_type{});
+    for (; i + 6 < nfull; i += 2) {                       // steady state: tiles i + 5 and i + 6 exist and are full
+      merged(i, pa, pb, sB, dB, sA, dA, std::true_type{});
+      merged(i + 1, pb, pa, sA, dA, sB, dB, std::true_type{});
     }
+    asm volatile("s_nop 15\n\ts_nop 15" : "+v"(sA), "+v"(dA), "+v"(sB), "+v"(dB));   // (the same at the steady loop's exit)
     for (; i + 1 < nt; i += 2) {                          // the last few tiles: the same iteration with its edge conditions
-      iteration(i, pa, pb, std::false_type{});
-      iteration(i + 1, pb, pa, std::false_type{});
+      merged(i, pa, pb, sB, dB, sA, dA, std::false_type{});
+      merged(i + 1, pb, pa, sA, dA, sB, dB, std::false_type{});
     }
     if (i < nt) {
-      iteration(i, pa, pb, std::false_type{});
-      phase_y(sa, pb, pa, std::false_type{}, -1, 0, -1, std::false_type{});  // the last tile's products: nothing left to overlap
+      merged(i, pa, pb, sB, dB, sA, dA, std::false_type{});
+      phase_y(s_m1, pb);                                  // the last tile's products: nothing left to overlap
     } else {
-      phase_y(sa, pa, pb, std::false_type{}, -1, 0, -1, std::false_type{});
+      phase_y(s_m1, pa);
     }
   }
 
 #ifdef LCV_DKV3_STAMPS
   if (dbg_on && lane_now() == 0)
     for (int i = 0; i < 64; ++i)
-      g_dkv3_dbg[(wave ? 64 : 0) + i] = *reinterpret_cast<AS3X unsigned long long*>(lds + 6 * STAGE + wave * 1024 + i * 8);
+      g_dkv3_dbg[(wave ? 64 : 0) + i] = *reinterpret_cast<AS3X unsigned long long*>(lds + 7 * STAGE + wave * 1024 + i * 8);
 #endif
   // ---- epilogue: acc[d][e] = dX^T[dim = 32 d + (e & 3) + 8 (e >> 2) + 4 h][key = lane & 31] ----
   const int ln = lane_now();
@@ -406,9 +479,9 @@ int attn_bwd_dkv3_launch(const void* q, const void* k, const void* v, const void
   p.dk_sb = dk_sb; p.dk_sn = dk_sn; p.dk_sh = dk_sh; p.dv_sb = dv_sb; p.dv_sn = dv_sn; p.dv_sh = dv_sh;
   p.scale = scale; p.accumulate_kv = accumulate_kv;
 #ifdef LCV_DKV3_STAMPS
-  const size_t lds = 6 * (2 * 32 * 256 + 2 * 32 * 4) + 4096;
+  const size_t lds = 7 * (2 * 32 * 256 + 2 * 32 * 4) + 4096;
 #else
-  const size_t lds = 6 * (2 * 32 * 256 + 2 * 32 * 4);
+  const size_t lds = 7 * (2 * 32 * 256 + 2 * 32 * 4);
 #endif
   static bool attr_set = false;
   if (!attr_set) {
