@@ -403,6 +403,10 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_fwd_kernel(const AttnFwdPara
   }
 }
 
+int attn_fwd_w64_launch(const void* q, const void* k, const void* v, void* o, float* lse, int64_t B, int64_t H, int64_t Nq,
+                        int64_t Nk, int64_t q_sb, int64_t q_sn, int64_t q_sh, int64_t k_sb, int64_t k_sn, int64_t k_sh,
+                        int64_t v_sb, int64_t v_sn, int64_t v_sh, int64_t o_sb, int64_t o_sn, int64_t o_sh, float scale,
+                        int xcd_ok, hipStream_t s);
 int attn_fwd_pipe_launch(const void* q, const void* k, const void* v, void* o, float* lse, int64_t B, int64_t H, int64_t Nq,
                          int64_t Nk, int64_t q_sb, int64_t q_sn, int64_t q_sh, int64_t k_sb, int64_t k_sn, int64_t k_sh,
                          int64_t v_sb, int64_t v_sn, int64_t v_sh, int64_t o_sb, int64_t o_sn, int64_t o_sh, float scale,
@@ -458,6 +462,12 @@ extern "C" int lcv_attn_fwd(const void* q, const void* k, const void* v, void* o
   // (its LDS-DMA addresses are a scalar base + 32-bit per-lane byte offsets: one (batch, head)'s rows must span < 4 GiB)
   const bool span32 = (uint64_t)Nk * (uint64_t)(k_sn > v_sn ? k_sn : v_sn) * 2 < (1ull << 32) &&
                       (uint64_t)Nq * (uint64_t)q_sn * 2 < (1ull << 32);
+  const char* we = getenv("LCV_ATTN_FWD_W64");  // A/B knob: 1 = 64 query rows per wave on one wave per SIMD (attn_fwd_w64.hip)
+  if (unit && Nk > 512 && span32 && we && we[0] == '1') {
+    g_last_attn_kernel = "attn_fwd_w64_kernel";
+    return attn_fwd_w64_launch(q, k, v, o, lse, B, H, Nq, Nk, q_sb, q_sn, q_sh, k_sb, k_sn, k_sh, v_sb, v_sn, v_sh, o_sb, o_sn,
+                               o_sh, scale, !(xe && xe[0] == '0'), (hipStream_t)stream);
+  }
   if (unit && Nk > 512 && span32 && !(pe2 && pe2[0] == '0') && prio == 0 && var == 1) {
     g_last_attn_kernel = "attn_fwd_pipe_kernel";
     return attn_fwd_pipe_launch(q, k, v, o, lse, B, H, Nq, Nk, q_sb, q_sn, q_sh, k_sb, k_sn, k_sh, v_sb, v_sn, v_sh, o_sb, o_sn,

@@ -54,6 +54,23 @@ struct AttnFwdPipeParams {
 
 #define PIPE_RESCALE_THR 6.0f
 
+// Lab builds only (scratch/attn_lab/build_pipe.sh; results are wrong, only the clock is read): leave one class of instructions out
+// of the steady loop to price it.  The product never defines any of these.
+#if defined(LCV_PIPE_NO_KREAD)
+#define PIPE_LAB_KREAD(i) false
+#elif defined(LCV_PIPE_HALF_KREAD)
+#define PIPE_LAB_KREAD(i) (((i) & 2) == 0)
+#else
+#define PIPE_LAB_KREAD(i) true
+#endif
+#if defined(LCV_PIPE_NO_VREAD)
+#define PIPE_LAB_VREAD(j) false
+#elif defined(LCV_PIPE_HALF_VREAD)
+#define PIPE_LAB_VREAD(j) (((j) & 1) == 0)
+#else
+#define PIPE_LAB_VREAD(j) true
+#endif
+
 // Diagnostic build only (scratch/attn_lab/build_pipe.sh defines LCV_ATTN_STAMPS; the product never does): s_memtime stamps of
 // waves 0 and 4 of one block at five points of eight consecutive iterations, written to a buffer nothing else reads.
 #ifdef LCV_ATTN_STAMPS
@@ -354,8 +371,8 @@ __global__ __launch_bounds__(512) void attn_fwd_pipe_kernel(const AttnFwdPipePar
     // ---------------- phase 1: 16 score MFMAs of tile t+1; exp2 / sums / packing of elements 0..23 of tile t ----------------
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      if (i + PD < 16) kfr[(i + PD) % RING] = read_k(kb, i + PD);
-      if (i >= 16 - PD) vfr[i - (16 - PD)] = read_v(i - (16 - PD));   // first fragments of V(t) (landed since the last barrier)
+      if (i + PD < 16 && PIPE_LAB_KREAD(i + PD)) kfr[(i + PD) % RING] = read_k(kb, i + PD);
+      if (i >= 16 - PD && PIPE_LAB_VREAD(i - (16 - PD))) vfr[i - (16 - PD)] = read_v(i - (16 - PD));   // first fragments of V(t) (landed since the last barrier)
       if (i == 0) {
         // both chains' first MFMAs in ONE statement, D != C (hipcc would pick the tied form and copy 16 registers per chain):
         // the resident -m_run tuple is read as C and survives
@@ -371,6 +388,7 @@ __global__ __launch_bounds__(512) void attn_fwd_pipe_kernel(const AttnFwdPipePar
       // exps of this gap: elements [e_lo, e_hi); the sums and packs trail one gap behind
       const int e_lo = (3 * i + 1) / 2, e_hi = (3 * (i + 1) + 1) / 2;
       const int a_lo = i ? (3 * (i - 1) + 1) / 2 : 0, a_hi = i ? e_lo : 0;
+#ifndef LCV_PIPE_NO_VALU
 #pragma unroll
       for (int j = 0; j < 24; ++j)
         if (j >= e_lo && j < e_hi) ex[j] = g_exp2(SC(c0, c1, j));
@@ -380,6 +398,13 @@ __global__ __launch_bounds__(512) void attn_fwd_pipe_kernel(const AttnFwdPipePar
           psum = (j == 0) ? ex[0] : g_add(psum, ex[j]);
           if (j & 1) pw[j >> 1] = g_pack(ex[j - 1], ex[j]);
         }
+#else
+      if (i == 0) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) asm volatile("" : "=v"(pw[j]));
+        (void)e_lo; (void)e_hi; (void)a_lo; (void)a_hi;
+      }
+#endif
       SCHED_FENCE();
     }
     PIPE_STAMP(1)
@@ -394,18 +419,21 @@ __global__ __launch_bounds__(512) void attn_fwd_pipe_kernel(const AttnFwdPipePar
     SCHED_FENCE();
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-      if (j + PD < 16) vfr[(j + PD) % RING] = read_v(j + PD);
-      if (j >= 16 - PD) kfr[j - (16 - PD)] = read_k(kb_next, j - (16 - PD));   // first fragments of K(t+2) (unused after the last one)
+      if (j + PD < 16 && PIPE_LAB_VREAD(j + PD)) vfr[(j + PD) % RING] = read_v(j + PD);
+      if (j >= 16 - PD && PIPE_LAB_KREAD(j - (16 - PD))) kfr[j - (16 - PD)] = read_k(kb_next, j - (16 - PD));   // first fragments of K(t+2) (unused after the last one)
       const int kk = j >> 2;
       const u32x4 pbw = {pw[4 * kk], pw[4 * kk + 1], pw[4 * kk + 2], pw[4 * kk + 3]};
       oacc[j & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[j % RING], __builtin_bit_cast(bf16x8, pbw), oacc[j & 3], 0, 0, 0);
       SCHED_FENCE();
       // the four LDS-DMA pieces of this iteration: K(t+3) into K(t+1)'s buffer, V(t+2) into V(t-1)'s slot (both free since
       // the barrier above); they are waited for at the next barrier, a whole iteration away
+#ifndef LCV_PIPE_NO_DMA
       if (j == 0 && has_k3) dma_one(KOP{}, I0{}, (PAR ^ 1) * TILE, t + 3);
       if (j == 1 && has_k3) dma_one(KOP{}, I1{}, (PAR ^ 1) * TILE, t + 3);
       if (j == 2 && has_v2) dma_one(VOP{}, I0{}, v_dst, t + 2);
       if (j == 3 && has_v2) dma_one(VOP{}, I1{}, v_dst, t + 2);
+#endif
+#ifndef LCV_PIPE_NO_VALU
       if (j == 0) {   // element 23 (exp'ed in the last gap of phase 1)
         psum = g_add(psum, ex[23]);
         pw[11] = g_pack(ex[22], ex[23]);
@@ -427,6 +455,7 @@ __global__ __launch_bounds__(512) void attn_fwd_pipe_kernel(const AttnFwdPipePar
       if (j == 3) mxb = g_max3(n1[1], n1[2], n1[3]);
       if (j > 3 && j < 10) mxb = g_max3(mxb, n1[2 * (j - 2)], n1[2 * (j - 2) + 1]);
       if (j == 10) mx = pipe_half_max(g_max3(mxa, mxb, mxb));   // + the partner half's keys (one v_permlane32_swap)
+#endif
       SCHED_FENCE();
     }
     PIPE_STAMP(3)
