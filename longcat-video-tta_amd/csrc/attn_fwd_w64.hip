@@ -41,6 +41,18 @@ struct AttnFwdW64Params {
 
 #define W64_RESCALE_THR 6.0f
 
+// Lab builds only (scratch/attn_lab/build_w64.sh ablation; results are wrong, only the clock is read).  The product defines none.
+#ifdef LCV_W64_NO_KREAD
+#define W64_LAB_KREAD false
+#else
+#define W64_LAB_KREAD true
+#endif
+#ifdef LCV_W64_NO_VREAD
+#define W64_LAB_VREAD false
+#else
+#define W64_LAB_VREAD true
+#endif
+
 #ifdef LCV_ATTN_STAMPS
 __device__ unsigned long long* g_w64_dbg = nullptr;
 __device__ int g_w64_dbg_block = 0;
@@ -74,6 +86,8 @@ __device__ __forceinline__ float w64_half_sum(float v) {
 __device__ __forceinline__ float w_exp2(float x) { float y; asm volatile("v_exp_f32 %0, %1" : "=v"(y) : "v"(x)); return y; }
 __device__ __forceinline__ float w_add(float a, float b) { float y; asm volatile("v_add_f32 %0, %1, %2" : "=v"(y) : "v"(a), "v"(b)); return y; }
 __device__ __forceinline__ float w_max3(float a, float b, float c) { float y; asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(y) : "v"(a), "v"(b), "v"(c)); return y; }
+typedef __attribute__((ext_vector_type(2))) float f32x2w;
+__device__ __forceinline__ f32x2w w_pk_add(f32x2w a, f32x2w b) { f32x2w y; asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(y) : "v"(a), "v"(b)); return y; }
 __device__ __forceinline__ unsigned w_pack(float lo, float hi) { unsigned y; asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(y) : "v"(lo), "v"(hi)); return y; }
 
 // GUARD: wait states in front of the MFMA wherever hipcc may have placed a register copy of one of its operands right before the
@@ -157,7 +171,10 @@ __global__ __launch_bounds__(256) void attn_fwd_w64_kernel(const AttnFwdW64Param
     unsigned off = which ? voff[i] : koff[i];
     if (!known_full && tile == nt - 1) off = last_off(i, sn);
     else base += (int64_t)tile * (128 * sn);
-    lcv_lds_dma16_sv(off, base, lds_wave + (unsigned)dst_tile + 1024u * i);
+    // (M0 carries the LDS destination; nothing else in this kernel uses it, so it is declared clobbered instead of saved and
+    // restored around every request: two scalar instructions less per request on a wave whose issue slots are the budget)
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :: "v"(off), "s"(base), "s"(lds_wave + (unsigned)dst_tile + 1024u * i) : "memory", "m0");
   };
   auto dma_tile = [&](int which, int dst_tile, int tile) __attribute__((always_inline)) {
 #pragma unroll
@@ -179,15 +196,16 @@ __global__ __launch_bounds__(256) void attn_fwd_w64_kernel(const AttnFwdW64Param
     for (int half = 0; half < 2; ++half)
 #pragma unroll
       for (int d = 0; d < 4; ++d)
-        v_off[half][d] = V_REGION + slot * TILE + 256 * (4 * hh + 8 * half + q4) + 8 * (p4 & 1) + 64 * (d ^ q4) + 16 * ((2 * g1 + (p4 >> 1)) ^ (hh + 2 * half));
+        v_off[half][d] = (int)(unsigned)(uintptr_t)lds + V_REGION + slot * TILE + 256 * (4 * hh + 8 * half + q4) + 8 * (p4 & 1) + 64 * (d ^ q4) +
+                         16 * ((2 * g1 + (p4 >> 1)) ^ (hh + 2 * half));   // ABSOLUTE LDS byte address: no base add per read
   };
   set_read_offsets(lane, 2);   // (V slot 2: iteration 0 rotates the offsets to slot 0)
   auto read_k = [&](const lds_u8w* kb, int f) __attribute__((always_inline)) -> bf16x8 {   // K fragment f: k-step f >> 1, key block f & 1
     return *reinterpret_cast<const AS3W bf16x8*>(kb + (f & 1) * 32 * 256 + k_off[f >> 1]);
   };
   auto read_v = [&](int g) __attribute__((always_inline)) -> bf16x8 {   // V^T fragment g: k-step g >> 2, dim block g & 3, of the slot the offsets point at
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((AS3W s16x4*)(lds + 4096 * (g >> 2) + v_off[0][g & 3]));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((AS3W s16x4*)(lds + 4096 * (g >> 2) + v_off[1][g & 3]));
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((AS3W s16x4*)(uintptr_t)(unsigned)(v_off[0][g & 3] + 4096 * (g >> 2)));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((AS3W s16x4*)(uintptr_t)(unsigned)(v_off[1][g & 3] + 4096 * (g >> 2)));
     return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
   };
 
@@ -246,9 +264,9 @@ __global__ __launch_bounds__(256) void attn_fwd_w64_kernel(const AttnFwdW64Param
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(s[0][0]), "+v"(s[0][1]), "+v"(s[1][0]), "+v"(s[1][1]));
   };
   // row max of a query block's score tile relative to its running max, and the (rare) rescale it may trigger
-  auto settle = [&](f32x16 (&s)[2][2], auto nb_c, float mx, bool first) __attribute__((always_inline)) {
+  auto settle = [&](f32x16 (&s)[2][2], auto nb_c, float mx, bool first, bool need) __attribute__((always_inline)) {
     constexpr int nb = decltype(nb_c)::value;
-    if (__builtin_amdgcn_ballot_w64(mx > W64_RESCALE_THR) != 0ull || first) {
+    if (need || first) {   // need: some lane's row max exceeds the threshold (a ballot the caller took inside an MFMA gap)
       fence_o();
       const float d = first ? mx : fmaxf(mx, 0.f);
       const float alpha = __builtin_amdgcn_exp2f(-d);
@@ -262,13 +280,21 @@ __global__ __launch_bounds__(256) void attn_fwd_w64_kernel(const AttnFwdW64Param
       for (int e = 0; e < 16; ++e) {
         s[0][nb][e] -= d;
         s[1][nb][e] -= d;
-        minit[nb][e] = -m_run[nb];
+        // an in-place update as far as hipcc can tell: a fresh splat here made it copy the whole tuple (8 v_mov_b64 per query
+        // block) on the COMMON path of every iteration to merge the two versions
+        asm volatile("v_mov_b32 %0, %1" : "+v"(minit[nb][e]) : "v"(-m_run[nb]));
       }
       fence_o();
     }
   };
 
-  constexpr int PD = 2, RING = PD + 1;   // fragments are requested PD fragments (= 2 PD MFMAs) ahead of their first use
+#ifndef W64_PD
+#define W64_PD 2
+#endif
+#ifndef W64_DMA_STRIDE
+#define W64_DMA_STRIDE 1
+#endif
+  constexpr int PD = W64_PD, RING = PD + 1;   // fragments are requested PD fragments (= 2 PD MFMAs) ahead of their first use
   bf16x8 kfr[RING], vfr[RING];
   int v_slot = 2;
   auto next_v_slot = [&]() __attribute__((always_inline)) -> int {
@@ -303,7 +329,7 @@ __global__ __launch_bounds__(256) void attn_fwd_w64_kernel(const AttnFwdW64Param
       for (int e = 1; e < 16; ++e) mx = fmaxf(mx, sa[0][nb][e]);
 #pragma unroll
       for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sa[1][nb][e]);
-      settle(sa, nb_c, w64_half_max(mx), true);
+      settle(sa, nb_c, w64_half_max(mx), true, true);
     };
     first_settle(std::integral_constant<int, 0>{});
     first_settle(std::integral_constant<int, 1>{});
@@ -326,8 +352,8 @@ __global__ __launch_bounds__(256) void attn_fwd_w64_kernel(const AttnFwdW64Param
     const int v_delta = next_v_slot();                // v_slot == t % 3 from here on
     const int v_dst = V_REGION + ((v_slot == 0) ? 2 : v_slot - 1) * TILE;   // slot (t + 2) % 3
     W64_STAMP(0)
-    float psum[2] = {0.f, 0.f};
-    float ex[2][32];      // P(t) in fp32
+    f32x2w psum[2];       // row sums of P(t), even / odd elements apart (v_pk_add_f32: one instruction per pair)
+    f32x2w ex[2][16];     // P(t) in fp32: pair m = elements (2m, 2m + 1)
     unsigned pw[2][16];   // P(t) as packed bf16 pairs: word m = elements (2m, 2m + 1)
     SCHED_FENCE();
     // ---------------- phase 1: 32 score MFMAs of tile t+1; exp2 / sums / packs of elements 0..23 of both query blocks ----------
@@ -335,8 +361,8 @@ __global__ __launch_bounds__(256) void attn_fwd_w64_kernel(const AttnFwdW64Param
     for (int i = 0; i < 32; ++i) {
       const int f = i >> 1, nb = i & 1;               // fragment f = (k-step f >> 1, key block f & 1) feeds MFMAs 2 f, 2 f + 1
       if (nb == 0) {
-        if (f + PD < 16) kfr[(f + PD) % RING] = read_k(kb, f + PD);
-        if (f >= 16 - PD) vfr[f - (16 - PD)] = read_v(f - (16 - PD));   // first fragments of V(t) (landed since the last barrier)
+        if (f + PD < 16 && W64_LAB_KREAD) kfr[(f + PD) % RING] = read_k(kb, f + PD);
+        if (f >= 16 - PD && W64_LAB_VREAD) vfr[f - (16 - PD)] = read_v(f - (16 - PD));   // first fragments of V(t) (landed since the last barrier)
       }
       if (f < 2) {
         if (STEADY && i >= 1) mfma_s_first<false>(n[f & 1][nb], minit[nb], kfr[f % RING], qf[nb][0]);
@@ -351,20 +377,30 @@ __global__ __launch_bounds__(256) void attn_fwd_w64_kernel(const AttnFwdW64Param
       // exps of this gap: indices [e_lo, e_hi) of 48 (index -> query block idx & 1, element idx >> 1); sums / packs trail one gap
       const int e_lo = (3 * i + 1) / 2, e_hi = (3 * (i + 1) + 1) / 2;
       const int a_lo = i ? (3 * (i - 1) + 1) / 2 : 0, a_hi = i ? e_lo : 0;
+#ifdef LCV_W64_NO_VALU
+      if (i == 0) {
+#pragma unroll
+        for (int m = 0; m < 16; ++m) asm volatile("" : "=v"(pw[0][m]), "=v"(pw[1][m]));
+      }
+#else
 #pragma unroll
       for (int u = 0; u < 2; ++u) {                   // (at most two per gap; fixed trip count so that the loop unrolls)
         const int x = e_lo + u;
-        if (x < e_hi) ex[x & 1][x >> 1] = w_exp2(SCW(c, x & 1, x >> 1));
+        if (x < e_hi) ex[x & 1][x >> 2][(x >> 1) & 1] = w_exp2(SCW(c, x & 1, x >> 1));
       }
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int x = a_lo + u;
         if (x < a_hi) {
           const int b_ = x & 1, j = x >> 1;
-          psum[b_] = (j == 0) ? ex[b_][0] : w_add(psum[b_], ex[b_][j]);
-          if (j & 1) pw[b_][j >> 1] = w_pack(ex[b_][j - 1], ex[b_][j]);
+          if (j & 1) {                                  // pair j >> 1 of block b_ is complete
+            pw[b_][j >> 1] = w_pack(ex[b_][j >> 1][0], ex[b_][j >> 1][1]);
+            if (j == 3) psum[b_] = w_pk_add(ex[b_][0], ex[b_][1]);
+            else if (j > 3) psum[b_] = w_pk_add(psum[b_], ex[b_][j >> 1]);
+          }
         }
       }
+#endif
       SCHED_FENCE();
     }
     W64_STAMP(1)
@@ -376,14 +412,15 @@ __global__ __launch_bounds__(256) void attn_fwd_w64_kernel(const AttnFwdW64Param
     dma_wait_and_barrier();
     W64_STAMP(2)
     // ---------------- phase 2: 32 PV MFMAs of tile t; the rest of P(t); row max of S(t+1); next requests and fragments --------
-    float mxa[2] = {0.f, 0.f}, mxb[2] = {0.f, 0.f};
+    float mxa[2] = {0.f, 0.f}, mxb[2] = {0.f, 0.f}, mxh[2] = {0.f, 0.f};
+    bool need[2] = {false, false};
     SCHED_FENCE();
 #pragma unroll
     for (int j = 0; j < 32; ++j) {
       const int g = j >> 1, nb = j & 1;               // fragment g = (k-step g >> 2, dim block g & 3) feeds MFMAs 2 g, 2 g + 1
       if (nb == 0) {
-        if (g + PD < 16) vfr[(g + PD) % RING] = read_v(g + PD);
-        if (g >= 16 - PD) kfr[g - (16 - PD)] = read_k(kb_next, g - (16 - PD));   // first fragments of K(t+2)
+        if (g + PD < 16 && W64_LAB_VREAD) vfr[(g + PD) % RING] = read_v(g + PD);
+        if (g >= 16 - PD && W64_LAB_KREAD) kfr[g - (16 - PD)] = read_k(kb_next, g - (16 - PD));   // first fragments of K(t+2)
       }
       const int kk = g >> 2;
       const u32x4 pbw = {pw[nb][4 * kk], pw[nb][4 * kk + 1], pw[nb][4 * kk + 2], pw[nb][4 * kk + 3]};
@@ -392,26 +429,18 @@ __global__ __launch_bounds__(256) void attn_fwd_w64_kernel(const AttnFwdW64Param
       SCHED_FENCE();
       // the eight LDS-DMA requests of this iteration: K(t+3) into K(t+1)'s buffer, V(t+2) into V(t-1)'s slot (both free since the
       // barrier above); waited for at the next barrier, a whole iteration away
-      if (j < 4) { if (has_k3) dma_one(KOP, j & 3, (PAR ^ 1) * TILE, t + 3, STEADY); }
-      else if (j < 8) { if (has_v2) dma_one(VOP, j & 3, v_dst, t + 2, STEADY); }
-      // quarter 3: one exp per gap, its sum / pack two gaps later (the same query block's next turn)
-      if (j == 0) {   // index 47 (query block 1, element 23) was exp'ed in the last gap of phase 1
-        psum[1] = w_add(psum[1], ex[1][23]);
-        pw[1][11] = w_pack(ex[1][22], ex[1][23]);
+#ifndef LCV_W64_NO_DMA
+      if (j % W64_DMA_STRIDE == 0 && j / W64_DMA_STRIDE < 8) {
+        const int dj = j / W64_DMA_STRIDE;
+        if (dj < 4) { if (has_k3) dma_one(KOP, dj & 3, (PAR ^ 1) * TILE, t + 3, STEADY); }
+        else { if (has_v2) dma_one(VOP, dj & 3, v_dst, t + 2, STEADY); }
       }
+#endif
+#ifndef LCV_W64_NO_VALU
+      // row max of S(t+1) first (gaps 0..15: per query block 16 max3 over its 32 values, two chains of 8), then the exchange with
+      // the partner half and the ballot in gaps 16..19: nothing but two scalar branches is left behind the phase
       if (j < 16) {
-        const int b_ = j & 1, el = 24 + (j >> 1);
-        ex[b_][el] = w_exp2(SCW(c, b_, el));
-      }
-      if (j >= 2 && j < 18) {   // the exp of gap j - 2 (same query block)
-        const int b_ = j & 1, el = 24 + ((j - 2) >> 1);
-        psum[b_] = w_add(psum[b_], ex[b_][el]);
-        if (el & 1) pw[b_][el >> 1] = w_pack(ex[b_][el - 1], ex[b_][el]);
-      }
-      if (j == 18 || j == 19) l_run[j & 1] = w_add(l_run[j & 1], psum[j & 1]);
-      // row max of S(t+1), gaps 16..31: per query block 16 max3 over its 32 values (two chains of 8)
-      if (j >= 16) {
-        const int b_ = j & 1, s_ = (j - 16) >> 1;     // step 0..7 of block b_
+        const int b_ = j & 1, s_ = j >> 1;            // step 0..7 of block b_
         if (s_ == 0) {
           mxa[b_] = w_max3(n[0][b_][0], n[0][b_][1], n[0][b_][2]);
           mxb[b_] = w_max3(n[1][b_][0], n[1][b_][1], n[1][b_][2]);
@@ -420,14 +449,36 @@ __global__ __launch_bounds__(256) void attn_fwd_w64_kernel(const AttnFwdW64Param
           mxb[b_] = w_max3(mxb[b_], n[1][b_][2 * s_ + 1], n[1][b_][2 * s_ + 2]);
         } else {
           mxa[b_] = w_max3(mxa[b_], n[0][b_][15], mxb[b_]);
-          mxb[b_] = w_max3(mxa[b_], n[1][b_][15], n[1][b_][14]);
+          mxb[b_] = w_max3(mxa[b_], n[1][b_][15], n[1][b_][14]);   // (the full maximum: chain a folded in)
         }
       }
+      if (j == 16 || j == 17) mxh[j & 1] = w64_half_max(mxb[j & 1]);
+      if (j == 18 || j == 19) need[j & 1] = __builtin_amdgcn_ballot_w64(mxh[j & 1] > W64_RESCALE_THR) != 0ull;
+      // quarter 3 of P(t): index 47 (query block 1, element 23) was exp'ed in the last gap of phase 1; elements 24..31 one exp per
+      // gap in gaps 6..21, the sum / pack two gaps later (the same block's next turn); all packs exist before the k-step 3 MFMAs
+      if (j == 0) {
+        psum[1] = w_pk_add(psum[1], ex[1][11]);
+        pw[1][11] = w_pack(ex[1][11][0], ex[1][11][1]);
+      }
+      if (j >= 6 && j < 22) {
+        const int b_ = j & 1, el = 24 + ((j - 6) >> 1);
+        ex[b_][el >> 1][el & 1] = w_exp2(SCW(c, b_, el));
+      }
+      if (j >= 8 && j < 24) {
+        const int b_ = j & 1, el = 24 + ((j - 8) >> 1);
+        if (el & 1) {
+          psum[b_] = w_pk_add(psum[b_], ex[b_][el >> 1]);
+          pw[b_][el >> 1] = w_pack(ex[b_][el >> 1][0], ex[b_][el >> 1][1]);
+        }
+      }
+      if (j == 24 || j == 25) psum[j & 1][0] = w_add(psum[j & 1][0], psum[j & 1][1]);
+      if (j == 26 || j == 27) l_run[j & 1] = w_add(l_run[j & 1], psum[j & 1][0]);
+#endif
       SCHED_FENCE();
     }
     W64_STAMP(3)
-    settle(n, std::integral_constant<int, 0>{}, w64_half_max(mxb[0]), false);   // (mxb: the last step folded chain a in)
-    settle(n, std::integral_constant<int, 1>{}, w64_half_max(mxb[1]), false);
+    settle(n, std::integral_constant<int, 0>{}, mxh[0], false, need[0]);
+    settle(n, std::integral_constant<int, 1>{}, mxh[1], false, need[1]);
     W64_STAMP(4)
   };
 
