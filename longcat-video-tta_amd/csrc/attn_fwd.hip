@@ -462,8 +462,10 @@ extern "C" int lcv_attn_fwd(const void* q, const void* k, const void* v, void* o
   // (its LDS-DMA addresses are a scalar base + 32-bit per-lane byte offsets: one (batch, head)'s rows must span < 4 GiB)
   const bool span32 = (uint64_t)Nk * (uint64_t)(k_sn > v_sn ? k_sn : v_sn) * 2 < (1ull << 32) &&
                       (uint64_t)Nq * (uint64_t)q_sn * 2 < (1ull << 32);
-  const char* we = getenv("LCV_ATTN_FWD_W64");  // A/B knob: 1 = 64 query rows per wave on one wave per SIMD (attn_fwd_w64.hip)
-  if (unit && Nk > 512 && span32 && we && we[0] == '1') {
+  // default since round 3: 64 query rows per wave on one wave per SIMD (attn_fwd_w64.hip; equal to +4 % against the pipelined
+  // two-waves-per-SIMD kernel depending on the box, profiles/r03_attn_fwd_lab.md).  A/B knob: LCV_ATTN_FWD_W64=0 = attn_fwd_pipe.hip
+  const char* we = getenv("LCV_ATTN_FWD_W64");
+  if (unit && Nk > 512 && span32 && !(we && we[0] == '0') && !(pe2 && pe2[0] == '0') && prio == 0 && var == 1) {
     g_last_attn_kernel = "attn_fwd_w64_kernel";
     return attn_fwd_w64_launch(q, k, v, o, lse, B, H, Nq, Nk, q_sb, q_sn, q_sh, k_sb, k_sn, k_sh, v_sb, v_sn, v_sh, o_sb, o_sn,
                                o_sh, scale, !(xe && xe[0] == '0'), (hipStream_t)stream);
