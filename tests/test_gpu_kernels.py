@@ -133,6 +133,43 @@ def test_attention_log2_prescaled_q(B, H, Nq, Nk):
     assert torch.allclose(lse.cpu(), torch.logsumexp(s, dim=-1), atol=2e-4, rtol=1e-5)
 
 
+@pytest.mark.parametrize("B,H,Nq,Nk", [(1, 2, 600, 700), (2, 3, 257, 577), (1, 1, 64, 1024), (1, 2, 333, 641), (2, 1, 96, 3000)])
+def test_attention_64_rows_per_wave_kernel_is_the_default_and_equals_the_two_wave_kernel(B, H, Nq, Nk, monkeypatch):
+    """`attn_fwd_w64_kernel` (one wave per SIMD, 64 query rows per wave, asm-issued MFMAs: csrc/attn_fwd_w64.hip) takes every
+    unit-scale call with more than 512 keys.  Inputs as the DiT hands them over: q / k / v as strided slots of packed buffers,
+    q pre-scaled; two key rows spiked at different places so that EACH of a wave's two query blocks goes through the deferred
+    rescale (the one path that moves O between AGPRs and VGPRs around asm MFMAs), ragged last tiles in keys and queries.
+    Checked against fp32 softmax and against the two-waves-per-SIMD kernel (same operand maps; only the order of the fp32 row
+    sum differs), and twice for the same bits."""
+    ops, orc = _ops(), _orc()
+    from lcv_hip import lib as L
+    D = 128
+    c = ops.log2_qscale(D ** -0.5)
+    qk = torch.zeros(B, max(Nq, Nk), 2, H, D, dtype=BF16)
+    qk[:, :Nq, 0] = (_randn(B, Nq, H, D, seed=31).float() * c).to(BF16)
+    qk[:, :Nk, 1] = _randn(B, Nk, H, D, seed=32)
+    qkv = torch.zeros(B, Nk, 3, H, D, dtype=BF16)
+    qkv[:, :, 2] = _randn(B, Nk, H, D, seed=33)
+    qk[0, Nk // 3, 1] *= 7.0                      # every query's maximum jumps here ...
+    qk[0, (3 * Nk) // 4, 1, :, :] = qk[0, 5, 0, :, :].float().mul(40.0).to(BF16)   # ... again for query 5 only (block 0 of wave 0) ...
+    qk[0, Nk // 2, 1, :, :] = qk[0, 40, 0, :, :].float().mul(40.0).to(BF16)        # ... and for query 40 only (block 1 of wave 0)
+    qd, kd, vd = qk.to(DEV)[:, :Nq, 0], qk.to(DEV)[:, :Nk, 1], qkv.to(DEV)[:, :, 2]
+    monkeypatch.delenv("LCV_ATTN_FWD_W64", raising=False)
+    o, lse = ops.attention(qd, kd, vd, ops.LN2, need_lse=True)
+    assert L.load().lcv_attn_fwd_last_kernel().decode() == "attn_fwd_w64_kernel"
+    o_again, lse_again = ops.attention(qd, kd, vd, ops.LN2, need_lse=True)
+    assert torch.equal(o, o_again) and torch.equal(lse, lse_again)
+    monkeypatch.setenv("LCV_ATTN_FWD_W64", "0")
+    o2, lse2 = ops.attention(qd, kd, vd, ops.LN2, need_lse=True)
+    assert L.load().lcv_attn_fwd_last_kernel().decode() == "attn_fwd_pipe_kernel"
+    assert rel_l2(o, o2.float()) < 1e-4 and torch.allclose(lse, lse2, atol=2e-5, rtol=1e-6)
+    qf, kf, vf = qk[:, :Nq, 0].permute(0, 2, 1, 3), qk[:, :Nk, 1].permute(0, 2, 1, 3), qkv[:, :, 2].permute(0, 2, 1, 3)
+    ref = orc.sdpa(qf, kf, vf, ops.LN2)
+    assert rel_l2(o.permute(0, 2, 1, 3), ref) < 6e-3
+    s = (qf.float() @ kf.float().transpose(-1, -2)) * ops.LN2
+    assert torch.allclose(lse.cpu(), torch.logsumexp(s, dim=-1), atol=3e-4, rtol=1e-5)
+
+
 def test_lse_merge_of_key_ranges_equals_the_one_call_attention():
     """Sequence parallelism's overlap path (`LCV_SP_OVERLAP=1`, lcv_hip/autograd_ops.py::_sp_attention_overlapped) attends the
     local keys while the gather is in flight and merges the partial results through their log-sum-exps.  The merge assumes
