@@ -193,8 +193,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
       }
     }
     // dS' = P * (dP - delta), P = exp2(S - lse): the scale is applied to dQ once, in the epilogue.  (Starting the dP accumulators
-    // at -delta, as the scores start at -lse, was measured in round 3: 23.31 vs 23.01 ms per layer - the zero start is an inline
-    // constant of the first MFMA, a -delta start is 32 v_mov per tile in front of the chains; not kept.)
+    // at -delta, as the scores start at -lse, saves the 32 subtractions but needs a second resident 16-register tuple: the loop
+    // sits at 254 registers and the tuple put 11 scratch accesses into it - 23.31 vs 23.01 ms per layer, round 3; not kept.)
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       s0[e] = __builtin_amdgcn_exp2f(s0[e]) * (d0[e] - delta_q);
