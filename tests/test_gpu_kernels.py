@@ -133,7 +133,8 @@ def test_attention_log2_prescaled_q(B, H, Nq, Nk):
     assert torch.allclose(lse.cpu(), torch.logsumexp(s, dim=-1), atol=2e-4, rtol=1e-5)
 
 
-@pytest.mark.parametrize("B,H,Nq,Nk", [(1, 2, 600, 700), (2, 3, 257, 577), (1, 1, 64, 1024), (1, 2, 333, 641), (2, 1, 96, 3000)])
+@pytest.mark.parametrize("B,H,Nq,Nk", [(1, 2, 600, 700), (2, 3, 257, 577), (1, 1, 64, 1024), (1, 2, 333, 641), (2, 1, 96, 3000),
+                                       (1, 1, 130, 513), (1, 2, 65, 576), (1, 1, 256, 832)])   # 9 (ragged / full) and 13 key tiles
 def test_attention_64_rows_per_wave_kernel_is_the_default_and_equals_the_two_wave_kernel(B, H, Nq, Nk, monkeypatch):
     """`attn_fwd_w64_kernel` (one wave per SIMD, 64 query rows per wave, asm-issued MFMAs: csrc/attn_fwd_w64.hip) takes every
     unit-scale call with more than 512 keys.  Inputs as the DiT hands them over: q / k / v as strided slots of packed buffers,
