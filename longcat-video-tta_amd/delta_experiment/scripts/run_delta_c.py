@@ -28,12 +28,12 @@ def main(argv=None):
     args = build_parser().parse_args(argv)
     R.run_delta_method(
         args, "delta_c",
-        make_wrapper=lambda dit: DeltaCWrapper(dit, out_channels=dit.config.out_channels, delta_mode=args.delta_mode),
+        make_wrapper=lambda dit: DeltaCWrapper(dit, mode=args.delta_mode, out_channels=dit.config.out_channels),
         optimize_fn=lambda w, cond, train, pe, pm, device, es, tv=None: optimize_delta_c(
             w, cond, train, pe, pm, num_steps=args.delta_steps, lr=args.delta_lr, device=device, dtype=torch.bfloat16,
             early_stopper=es, train_latents_variants=tv),
         params_of=lambda w: [w.delta_out],
-        result_extra=lambda opt: {"delta_norm": opt["delta_norm"]},
+        result_extra=lambda opt: {"delta_out_norm": opt["delta_out_norm"]},
         summary_head={"delta_mode": args.delta_mode, "delta_steps": args.delta_steps, "delta_lr": args.delta_lr},
         file_suffix="delta_c")
 

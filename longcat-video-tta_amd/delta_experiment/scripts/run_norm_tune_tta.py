@@ -34,7 +34,7 @@ def main(argv=None):
         args, "norm_tune",
         make_wrapper=lambda dit: NormTuneForward(dit, args.norm_target, also_tune_delta=args.also_tune_delta),
         optimize_fn=lambda w, cond, train, pe, pm, device, es, tv=None: optimize_norm_params(
-            w, cond, train, pe, pm, num_steps=args.norm_steps, lr=args.norm_lr, device=device, dtype=torch.bfloat16,
+            w, w.tuned_params, cond, train, pe, pm, num_steps=args.norm_steps, lr=args.norm_lr, device=device, dtype=torch.bfloat16,
             early_stopper=es, train_latents_variants=tv),
         params_of=lambda w: w.tuned_params,
         result_extra=lambda opt: {k: opt[k] for k in ("norm_param_drift", "delta_norm") if k in opt},

@@ -2,9 +2,11 @@
 delta; B: one per block group, optionally on the hidden stream, partial dim, block subset) or to the output (C).
 
 Class / method / argument names follow delta_experiment/scripts/run_delta_a.py:88-305, run_delta_b.py:99-421 and
-run_delta_c.py:82-246.  Where the reference re-implements the DiT's outer forward for training and installs hooks for
-generation, this build uses the SAME hook points for both (the reference's own Series-25 check shows the two are
-equivalent): the DiT calls `t_embedder`, each block and itself through `__call__`, gradient checkpointing stays on the
+run_delta_c.py:82-246; every wrapper and loop here is checked on the GPU against fixtures minted from those classes
+themselves (tests/golden/make_delta_golden.py, tests/test_gpu_delta_golden.py).  Where the reference re-implements the DiT's
+outer forward for training and installs hooks for generation, this build uses the same hook points for both (the reference's
+own Series-25 check shows the two are equivalent) — with the one difference the reference has between them kept: delta-B's
+`delta_final` acts in the training forward only (run_delta_b.py:321-324 vs :175-212).  The DiT calls `t_embedder`, each block and itself through `__call__`, gradient checkpointing stays on the
 DiT (`dit.gradient_checkpointing`), and the gradient reaches delta through the fp32 adaLN island
 (`lcv_linear_f32_smallm_bwd`) and the modulation-table gradients of `lcv_adaln_modulate_bwd` / `lcv_gate_residual_bwd`.
 The optimizer is the fused clip + AdamW in its fp32 form (delta lives in fp32: run_delta_a.py:104).
@@ -87,7 +89,9 @@ class DeltaBWrapper(_HookedWrapper):
         self._full_dim = full_dim
         self._partial_dim = delta_dim if delta_dim is not None else full_dim
         self.deltas = nn.ParameterList([nn.Parameter(torch.zeros(self._partial_dim)) for _ in range(num_groups)])
-        self.delta_final = nn.Parameter(torch.zeros(self._partial_dim)) if delta_target == "hidden" else None
+        # the final-layer delta of the "hidden" target is sized by `delta_dim` itself (run_delta_b.py:149): without --delta-dim
+        # the reference's constructor raises TypeError from torch.zeros(None), and so does this one
+        self.delta_final = nn.Parameter(torch.zeros(delta_dim)) if delta_target == "hidden" else None
         per = math.ceil(self.num_blocks / num_groups)
         self.block_to_group = [min(i // per, num_groups - 1) for i in range(self.num_blocks)]
 
@@ -97,6 +101,22 @@ class DeltaBWrapper(_HookedWrapper):
         return F.pad(dv, (0, self._full_dim - dv.shape[0]))
 
     def apply_to_dit(self):
+        """The GENERATION hooks (run_delta_b.py:175-212): per-block deltas only.  The reference trains `delta_final` in its own
+        forward (:321-324) but never applies it while the video is generated; `forward()` below adds it, this method does not
+        (tests/golden/delta_wrappers.pt: `pred_gen` != `pred_train` for the hidden target)."""
+        self._install(training=False)
+
+    def forward(self, hidden_states, timestep, encoder_hidden_states, encoder_attention_mask=None,
+                num_cond_latents=0, **kwargs):
+        cache_kw = {k: kwargs[k] for k in self._CACHE_KW if k in kwargs}
+        self._install(training=True)
+        try:
+            return self.dit(hidden_states=hidden_states, timestep=timestep, encoder_hidden_states=encoder_hidden_states,
+                            encoder_attention_mask=encoder_attention_mask, num_cond_latents=num_cond_latents, **cache_kw)
+        finally:
+            self.remove_from_dit()
+
+    def _install(self, training: bool):
         self.remove_from_dit()
         pad = self._pad_delta
         for i, block in enumerate(self.dit.blocks):
@@ -116,7 +136,7 @@ class DeltaBWrapper(_HookedWrapper):
                         return (out[0] + e.to(out[0].dtype),) + out[1:]
                     return out + e.to(out.dtype)
                 self._hooks.append(block.register_forward_hook(post))
-        if self.delta_target == "hidden" and self.delta_final is not None:
+        if training and self.delta_target == "hidden" and self.delta_final is not None:
             df = self.delta_final
 
             def final_pre(_m, args, df=df):
@@ -129,10 +149,11 @@ class DeltaBWrapper(_HookedWrapper):
 class DeltaCWrapper(_HookedWrapper):
     """Output bias: pred + delta_out.view(1, C_out, 1, 1, 1); no gradient flows into the DiT."""
 
-    def __init__(self, dit: nn.Module, out_channels: int = 16, delta_mode: str = "per_channel"):
+    def __init__(self, dit: nn.Module, mode: str = "per_channel", out_channels: int = 16):   # run_delta_c.py:91-96
         super().__init__(dit)
-        if delta_mode != "per_channel":
-            raise ValueError(f"Unknown delta_mode: {delta_mode}")
+        self.mode = mode
+        if mode != "per_channel":
+            raise ValueError(f"Unknown mode: {mode}. Use 'per_channel'.")
         self.delta_out = nn.Parameter(torch.zeros(out_channels))
 
     def apply_to_dit(self):
@@ -244,8 +265,10 @@ def optimize_delta_b(wrapper: DeltaBWrapper, cond_latents, train_latents, prompt
     params = list(wrapper.deltas) + ([wrapper.delta_final] if wrapper.delta_final is not None else [])
     losses, est, es_state = _optimize(wrapper, params, True, cond_latents, train_latents, prompt_embeds, prompt_mask,
                                       num_steps, lr, device, dtype, early_stopper, train_latents_variants)
-    return {"losses": losses, "delta_norms": [d.detach().norm().item() for d in wrapper.deltas], "es_check_time": est,
-            "early_stopping_info": es_state}
+    delta_norms = [d.detach().norm().item() for d in wrapper.deltas]
+    if wrapper.delta_final is not None:   # run_delta_b.py:413-415
+        delta_norms.append(wrapper.delta_final.detach().norm().item())
+    return {"losses": losses, "delta_norms": delta_norms, "es_check_time": est, "early_stopping_info": es_state}
 
 
 def optimize_delta_c(wrapper: DeltaCWrapper, cond_latents, train_latents, prompt_embeds, prompt_mask, num_steps: int = 20,
@@ -254,8 +277,8 @@ def optimize_delta_c(wrapper: DeltaCWrapper, cond_latents, train_latents, prompt
                      train_latents_variants: Optional[List[Dict]] = None) -> Dict:
     losses, est, es_state = _optimize(wrapper, [wrapper.delta_out], False, cond_latents, train_latents, prompt_embeds,
                                       prompt_mask, num_steps, lr, device, dtype, early_stopper, train_latents_variants)
-    return {"losses": losses, "delta_norm": wrapper.delta_out.detach().norm().item(), "es_check_time": est,
-            "early_stopping_info": es_state}
+    return {"losses": losses, "delta_out_norm": wrapper.delta_out.detach().norm().item(),           # run_delta_c.py:240-246
+            "delta_out_values": wrapper.delta_out.detach().cpu().tolist(), "es_check_time": est, "early_stopping_info": es_state}
 
 
 def optimize_film_adapter(wrapper: FiLMAdapterWrapper, cond_latents, train_latents, prompt_embeds, prompt_mask,
@@ -296,12 +319,15 @@ class NormTuneForward(nn.Module):
     `remove_from_dit` exist so the shared runner loop can treat it like the hook-based wrappers (the tuned weights are in
     the modules already; `restore()` puts the per-job originals back for the next video)."""
 
-    def __init__(self, dit: nn.Module, norm_target: str = "all_norm", also_tune_delta: bool = False):
+    def __init__(self, dit: nn.Module, norm_target: Optional[str] = None, also_tune_delta: bool = False):
+        """`NormTuneForward(dit)` is the reference's constructor (run_norm_tune_tta.py:122-124: the parameter list lives in its
+        main()); with `norm_target` this wrapper does main()'s set-up too (:371-393: freeze, collect + unfreeze, optional
+        delta-A vector) and keeps the originals for the per-video reset."""
         super().__init__()
         self.dit = dit
         for p in dit.parameters():
             p.requires_grad = False
-        self.norm_params = collect_norm_params(dit, norm_target)
+        self.norm_params = collect_norm_params(dit, norm_target) if norm_target is not None else []
         for p in self.norm_params:
             p.requires_grad = True
         self._orig = [p.data.clone() for p in self.norm_params]
@@ -347,15 +373,19 @@ class NormTuneForward(nn.Module):
                         encoder_attention_mask=encoder_attention_mask, num_cond_latents=num_cond_latents, **cache_kw)
 
 
-def optimize_norm_params(wrapper: NormTuneForward, cond_latents, train_latents, prompt_embeds, prompt_mask, num_steps: int = 20,
-                         lr: float = 1e-3, device: str = "cuda", dtype: torch.dtype = torch.bfloat16,
-                         early_stopper: Optional[AnchoredEarlyStopper] = None,
+def optimize_norm_params(wrapper: NormTuneForward, norm_params: List[nn.Parameter], cond_latents, train_latents, prompt_embeds,
+                         prompt_mask, num_steps: int = 20, lr: float = 1e-3, device: str = "cuda",
+                         dtype: torch.dtype = torch.bfloat16, early_stopper: Optional[AnchoredEarlyStopper] = None,
                          train_latents_variants: Optional[List[Dict]] = None) -> Dict:
-    """run_norm_tune_tta.py:215-283: AdamW(eps 1e-15) over the norm parameters (bf16, like the module), global clip 1.0."""
-    losses, est, es_state = _optimize(wrapper, wrapper.tuned_params, False, cond_latents, train_latents, prompt_embeds,
+    """run_norm_tune_tta.py:215-283 (same positional order: the parameter list is the second argument): AdamW(eps 1e-15) over
+    `norm_params` (bf16 norm weights, plus the fp32 delta vector of --also-tune-delta), one global clip at 1.0.  Returns the
+    reference's keys (`losses`, `early_stopping_info`) and, beside them, the check time and how far the parameters moved."""
+    norm_params = list(norm_params)
+    losses, est, es_state = _optimize(wrapper, norm_params, False, cond_latents, train_latents, prompt_embeds,
                                       prompt_mask, num_steps, lr, device, dtype, early_stopper, train_latents_variants)
-    drift = sum((p.detach().float() - o.float()).norm().item() for p, o in zip(wrapper.norm_params, wrapper._orig))
-    out = {"losses": losses, "norm_param_drift": drift, "es_check_time": est, "early_stopping_info": es_state}
-    if wrapper.delta is not None:
+    out = {"losses": losses, "early_stopping_info": es_state, "es_check_time": est}
+    if getattr(wrapper, "_orig", None) and len(wrapper._orig) == len(wrapper.norm_params):
+        out["norm_param_drift"] = sum((p.detach().float() - o.float()).norm().item() for p, o in zip(wrapper.norm_params, wrapper._orig))
+    if getattr(wrapper, "delta", None) is not None:
         out["delta_norm"] = wrapper.delta.detach().norm().item()
     return out

@@ -105,6 +105,16 @@ def linear(x, w, b=None, rnd=_id):
     return rnd(y)
 
 
+def _lin(P, name, x, rnd=_id):
+    """The linear `name` of the parameter table P.  P[name] may be a callable — an nn.Module standing in for the
+    (weight, bias) pair (oracle/dit_module.py) — so that forward hooks and `setattr` replacement act on the oracle exactly
+    as they do on the upstream model (run_lora_tta.py:333, run_film_tta.py:146-163)."""
+    f = P.get(name)
+    if callable(f):
+        return rnd(f(x))
+    return linear(x, P[name + ".weight"], P.get(name + ".bias"), rnd)
+
+
 def sdpa(q, k, v, scale, rnd=_id):
     """q [B,H,Nq,D], k/v [B,H,Nk,D] -> [B,H,Nq,D]; softmax in fp32.  Heads are walked in groups when the score
     matrix would not fit (full-size clips evaluated with this file on the GPU box's card: tests/test_gpu_denoise_parity.py)."""
@@ -126,7 +136,7 @@ def self_attention(P: Dict[str, torch.Tensor], pre: str, x, shape, num_cond_late
                    kv_cache=None, return_kv=False):
     B, N, C = x.shape
     D = C // num_heads
-    qkv = linear(x, P[pre + "qkv.weight"], P.get(pre + "qkv.bias"), rnd)
+    qkv = _lin(P, pre + "qkv", x, rnd)
     qkv = qkv.view(B, N, 3, num_heads, D).permute(2, 0, 3, 1, 4)  # [3,B,H,N,D]
     q, k, v = qkv.unbind(0)
     q = rmsnorm_fp32(q, P[pre + "q_norm.weight"], rnd=rnd)
@@ -158,7 +168,7 @@ def self_attention(P: Dict[str, torch.Tensor], pre: str, x, shape, num_cond_late
         else:
             o = sdpa(q, k, v, scale, rnd)
     o = o.transpose(1, 2).reshape(B, N, C)
-    out = linear(o, P[pre + "proj.weight"], P.get(pre + "proj.bias"), rnd)
+    out = _lin(P, pre + "proj", o, rnd)
     if return_kv and kv_cache is None:
         return out, kv
     return out
@@ -172,8 +182,8 @@ def cross_attention(P, pre, x, y, y_seqlens: Sequence[int], num_cond_latents, sh
     if num_cond_latents is not None and num_cond_latents > 0:
         nc = num_cond_latents * (N // shape[0])
     xn = x[:, nc:]
-    q = linear(xn, P[pre + "q_linear.weight"], P.get(pre + "q_linear.bias"), rnd).view(B, N - nc, num_heads, D)
-    kv = linear(y, P[pre + "kv_linear.weight"], P.get(pre + "kv_linear.bias"), rnd).view(1, -1, 2, num_heads, D)
+    q = _lin(P, pre + "q_linear", xn, rnd).view(B, N - nc, num_heads, D)
+    kv = _lin(P, pre + "kv_linear", y, rnd).view(1, -1, 2, num_heads, D)
     k, v = kv.unbind(2)
     q = rmsnorm_fp32(q, P[pre + "q_norm.weight"], rnd=rnd)
     k = rmsnorm_fp32(k, P[pre + "k_norm.weight"], rnd=rnd)
@@ -186,29 +196,36 @@ def cross_attention(P, pre, x, y, y_seqlens: Sequence[int], num_cond_latents, sh
         o = sdpa(q[b].transpose(0, 1)[None], kb.transpose(0, 1)[None], vb.transpose(0, 1)[None], D ** -0.5, rnd)
         outs.append(o[0].transpose(0, 1).reshape(N - nc, C))
     o = torch.stack(outs, 0)
-    o = linear(o, P[pre + "proj.weight"], P.get(pre + "proj.bias"), rnd)
+    o = _lin(P, pre + "proj", o, rnd)
     if nc > 0:
         o = torch.cat([torch.zeros(B, nc, C, dtype=o.dtype, device=o.device), o], dim=1)
     return o
 
 
 def ffn(P, pre, x, rnd=_id):
-    g = linear(x, P[pre + "w1.weight"], None, rnd)
-    u = linear(x, P[pre + "w3.weight"], None, rnd)
+    g = _lin(P, pre + "w1", x, rnd)
+    u = _lin(P, pre + "w3", x, rnd)
     h = rnd(rnd(F.silu(g)) * u)
-    return linear(h, P[pre + "w2.weight"], None, rnd)
+    return _lin(P, pre + "w2", h, rnd)
 
 
 def adaln_table(P, pre, t):
-    """fp32 island: SiLU -> Linear(C_t -> k*C) on t [B, T, C_t] fp32."""
+    """fp32 island: SiLU -> Linear(C_t -> k*C) on t [B, T, C_t] fp32.  P[pre without the dot] may be the module itself
+    (oracle/dit_module.py), so FiLM's forward hooks on `adaLN_modulation` see its output (run_film_tta.py:146-163)."""
+    f = P.get(pre[:-1])
+    if callable(f):
+        return f(t.float())
     return F.silu(t.float()) @ P[pre + "1.weight"].float().t() + P[pre + "1.bias"].float()
 
 
 def block_forward(P, pre, x, y, t, y_seqlens, shape, num_cond_latents, num_heads, rnd=_id, kv_cache=None,
-                  return_kv=False, skip_crs_attn=False):
+                  return_kv=False, skip_crs_attn=False, mod_add=None):
     B, N, C = x.shape
     T = shape[0]
-    mod = adaln_table(P, pre + "adaLN_modulation.", t).unsqueeze(2)  # [B,T,1,6C]
+    mod = adaln_table(P, pre + "adaLN_modulation.", t)
+    if mod_add is not None:  # FiLM: a [6C] correction added to the adaLN output (run_film_tta.py:148-151)
+        mod = mod + mod_add.view(1, 1, -1).to(mod.dtype)
+    mod = mod.unsqueeze(2)  # [B,T,1,6C]
     sh_msa, sc_msa, g_msa, sh_mlp, sc_mlp, g_mlp = mod.chunk(6, dim=-1)
     x_m = modulate_fp32(x.view(B, T, -1, C), sh_msa, sc_msa, rnd=rnd).view(B, N, C)
     res = self_attention(P, pre + "attn.", x_m, shape, num_cond_latents, num_heads, rnd, kv_cache, return_kv)
@@ -285,14 +302,22 @@ def pack_text(y_emb: torch.Tensor, mask: Optional[torch.Tensor]):
 
 def dit_forward(P: Dict[str, torch.Tensor], cfg: dict, hidden_states, timestep, encoder_hidden_states,
                 encoder_attention_mask=None, num_cond_latents=0, bf16: bool = True, t_delta=None,
-                return_kv: bool = False, kv_cache_dict=None, skip_crs_attn: bool = False):
+                return_kv: bool = False, kv_cache_dict=None, skip_crs_attn: bool = False, adapters: Optional[dict] = None):
     """Full forward following run_delta_a.py:134-217.  cfg: depth, num_heads, patch_size, out_channels,
     text_tokens_zero_pad.
 
     `return_kv` / `skip_crs_attn` / `kv_cache_dict` are the three switches the pipeline's conditioning-frame KV
     cache uses [assumed-from-upstream]: the clean conditioning latents pass once at t = 0 without text
     cross-attention and every block keeps its (K pre-RoPE, V); a denoise step then runs over the noise tokens
-    only, with the cached cond K/V in front of the keys and RoPE positions continuing after them."""
+    only, with the cached cond K/V in front of the keys and RoPE positions continuing after them.
+
+    `adapters` — where the reference's delta / FiLM wrappers touch this forward (each entry optional; per-block lists hold a
+    tensor or None per block):
+      "block_t"      [depth] x [C_t]  added to the `t` a block receives ............ run_delta_b.py:294-298 (timestep target)
+      "block_hidden" [depth] x [C]    added to the hidden stream after a block ..... run_delta_b.py:311-318 (hidden target)
+      "final_hidden" [C]              added in front of the final layer ............ run_delta_b.py:321-324 (training forward only)
+      "film"         [depth] x [6C]   added to the block's adaLN output ............ run_film_tta.py:146-151
+      "out_delta"    [C_out]          added to the prediction ...................... run_delta_c.py:159-163"""
     rnd = bf16_round if bf16 else _id
     B, _, T, H, W = hidden_states.shape
     pt, ph, pw = cfg["patch_size"]
@@ -313,16 +338,32 @@ def dit_forward(P: Dict[str, torch.Tensor], cfg: dict, hidden_states, timestep, 
         mask = (mask * 0 + 1).to(mask.dtype)
     y, y_seqlens = pack_text(y, mask)
     kv_out = {} if return_kv else None
+    ad = adapters or {}
+
+    def _at(key, i):
+        lst = ad.get(key)
+        return None if lst is None else lst[i]
+
     for i in range(cfg["depth"]):
         kvc = None if kv_cache_dict is None else kv_cache_dict[i]
-        r = block_forward(P, f"blocks.{i}.", x, y, t, y_seqlens, (N_t, N_h, N_w), num_cond_latents,
-                          cfg["num_heads"], rnd, kv_cache=kvc, return_kv=return_kv, skip_crs_attn=skip_crs_attn)
+        bt = _at("block_t", i)
+        t_i = t if bt is None else t + bt.float().view(1, 1, -1)
+        r = block_forward(P, f"blocks.{i}.", x, y, t_i, y_seqlens, (N_t, N_h, N_w), num_cond_latents,
+                          cfg["num_heads"], rnd, kv_cache=kvc, return_kv=return_kv, skip_crs_attn=skip_crs_attn,
+                          mod_add=_at("film", i))
         if return_kv:
             x, kv_out[i] = r
         else:
             x = r
+        bh = _at("block_hidden", i)
+        if bh is not None:  # `hidden_states + delta.to(hidden_states.dtype)`: one rounding of delta, one of the sum
+            x = rnd(x + rnd(bh.float()).view(1, 1, -1))
+    if ad.get("final_hidden") is not None:
+        x = rnd(x + rnd(ad["final_hidden"].float()).view(1, 1, -1))
     x = final_layer(P, x, t, (N_t, N_h, N_w), rnd)
     out = unpatchify(x, N_t, N_h, N_w, (pt, ph, pw), cfg["out_channels"]).float()
+    if ad.get("out_delta") is not None:
+        out = out + ad["out_delta"].float().view(1, -1, 1, 1, 1)
     if return_kv:
         return out, kv_out
     return out

@@ -173,3 +173,153 @@ def warmup_lr(lr: float, step: int, warmup_steps: int, current: float) -> float:
     if step < warmup_steps and warmup_steps > 0:
         return lr * (step + 1) / warmup_steps
     return current
+
+
+# =====================================================================================================================
+# delta / FiLM / norm-tune wrappers and their optimise loops.  Pinned by tests/golden/delta_wrappers.pt, minted by
+# tests/golden/make_delta_golden.py from the reference's OWN wrapper classes and loops run over oracle/dit_module.OracleDiT
+# (checked in tests/test_delta_golden.py).  The functions below say WHERE each wrapper touches the DiT forward, in the
+# vocabulary of `dit_oracle.dit_forward(adapters=...)`.
+# =====================================================================================================================
+
+# ---- run_delta_a.py:104, 118-126 (generation hook on t_embedder) and :168 (training forward): the same place, every frame
+def delta_a_adapters(delta: torch.Tensor, depth: int, training: bool = True) -> dict:
+    """delta on the t_embedder output reaches every block AND the final layer: in dit_forward that is `t_delta`."""
+    return {"t_delta": delta}
+
+
+# ---- run_delta_b.py:143-157 (parameters, group map), :161-165 (zero padding), :175-212 (generation hooks), :276-324 (training)
+def delta_b_pad(dv: torch.Tensor, full_dim: int) -> torch.Tensor:
+    return dv if dv.shape[0] >= full_dim else F.pad(dv, (0, full_dim - dv.shape[0]))
+
+
+def delta_b_adapters(deltas: Sequence[torch.Tensor], delta_final: Optional[torch.Tensor], num_blocks: int, delta_target: str,
+                     full_dim: int, target_blocks: str = "all", training: bool = True) -> dict:
+    """Per-group deltas.  `training=True` is the wrapper's own forward (run_delta_b.py:276-324): in "hidden" mode it ALSO adds
+    `delta_final` in front of the final layer; `training=False` is what `apply_to_dit()` installs for generation
+    (:175-212): block hooks only — `delta_final` is trained but never applied when the video is generated."""
+    G = len(deltas)
+    groups = delta_b_block_to_group(num_blocks, G)
+    active = parse_target_blocks(target_blocks, num_blocks)
+    per_block = [delta_b_pad(deltas[groups[i]], full_dim) if (active is None or i in active) else None
+                 for i in range(num_blocks)]
+    if delta_target == "timestep":
+        return {"block_t": per_block}
+    ad = {"block_hidden": per_block}
+    if training and delta_final is not None:
+        ad["final_hidden"] = delta_b_pad(delta_final, full_dim)
+    return ad
+
+
+# ---- run_delta_c.py:117-131 (hook on the DiT output) and :159-163 (training forward)
+def delta_c_adapters(delta_out: torch.Tensor) -> dict:
+    return {"out_delta": delta_out}
+
+
+# ---- run_film_tta.py:129-141 (partial corrections expanded to the 6C adaLN layout) and :146-163 (hooks = training forward)
+def film_expand(corr: torch.Tensor, C: int, film_mode: str) -> torch.Tensor:
+    if film_mode == "full":
+        return corr
+    z = torch.zeros(C, dtype=corr.dtype, device=corr.device)
+    if film_mode == "scale_only":       # [scale_msa | scale_mlp]
+        return torch.cat([z, corr[:C], z, z, corr[C:], z])
+    if film_mode == "shift_scale":      # [shift_msa | scale_msa | shift_mlp | scale_mlp]
+        return torch.cat([corr[:C], corr[C:2 * C], z, corr[2 * C:3 * C], corr[3 * C:], z])
+    raise ValueError(f"Unknown film_mode: {film_mode}")
+
+
+def film_adapters(corrections: Sequence[torch.Tensor], num_blocks: int, C: int, film_mode: str) -> dict:
+    groups = film_group_idx(num_blocks, len(corrections))
+    return {"film": [film_expand(corrections[groups[i]], C, film_mode) for i in range(num_blocks)]}
+
+
+# ---- torch.nn.utils.clip_grad_norm_ on fp32 tensors (run_delta_a.py:267, run_delta_b.py:386-388, run_film_tta.py:305)
+def clip_grads_fp32(grads: List[torch.Tensor], max_norm: float) -> List[torch.Tensor]:
+    total = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(g, 2) for g in grads]), 2)
+    coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+    return [g * coef for g in grads]
+
+
+# ---- torch.optim.AdamW in fp32 as the delta scripts build it: AdamW(params, lr, betas=(0.9, 0.999), eps=1e-15) — the
+#      weight decay is torch's DEFAULT 0.01 (run_delta_a.py:242, run_delta_b.py:353-356, run_delta_c.py:198, run_film_tta.py:280)
+def adamw_step_fp32(p, g, m, v, step: int, lr: float, beta1=0.9, beta2=0.999, eps=1e-15, wd=0.01):
+    p = p * (1 - lr * wd)
+    m = m + (1 - beta1) * (g - m)
+    v = v * beta2 + (1 - beta2) * g * g
+    bc1, bc2 = 1 - beta1 ** step, 1 - beta2 ** step
+    denom = v.sqrt() / (bc2 ** 0.5) + eps
+    return p - (lr / bc1) * (m / denom), m, v
+
+
+# ---- torch.optim.SGD(momentum 0, weight_decay) as run_full_tta.py:137-143 builds it
+def sgd_step_fp32(p, g, lr: float, wd: float = 0.01):
+    return p - lr * (g + wd * p)
+
+
+def adapt_steps(loss_fn, params: List[torch.Tensor], num_steps: int, lr: float, per_param_clip: bool = False,
+                max_norm: float = 1.0, optimizer: str = "adamw", eps: float = 1e-15, wd: float = 0.01, warmup_steps: int = 0):
+    """The loop every optimise_* / finetune_* function of the reference shares (run_delta_a.py:256-270, run_delta_b.py:370-392,
+    run_delta_c.py:212-226, run_film_tta.py:292-308, run_norm_tune_tta.py:243-260, run_full_tta.py:157-187): zero grads, optional
+    linear warm-up of the LR (`lr*(step+1)/warmup`), loss, backward, clip (one global norm, or one norm PER PARAMETER for
+    delta-B), optimizer step.  `loss_fn(step, params)` -> scalar.  Returns (losses, params after every step, grads of every step)."""
+    ps = [p.detach().clone() for p in params]
+    ms = [torch.zeros_like(p) for p in ps]
+    vs = [torch.zeros_like(p) for p in ps]
+    losses, trace, gtrace = [], [], []
+    cur_lr = lr
+    for step in range(num_steps):
+        cur_lr = warmup_lr(lr, step, warmup_steps, cur_lr)
+        leaves = [p.clone().requires_grad_(True) for p in ps]
+        loss = loss_fn(step, leaves)
+        grads = torch.autograd.grad(loss, leaves, allow_unused=True)
+        live = [i for i, g in enumerate(grads) if g is not None]
+        gl = [grads[i] for i in live]
+        gtrace.append([None if g is None else g.detach().clone() for g in grads])
+        if per_param_clip:
+            gl = [clip_grads_fp32([g], max_norm)[0] for g in gl]
+        else:
+            gl = clip_grads_fp32(gl, max_norm)
+        for i, g in zip(live, gl):
+            if optimizer == "adamw":
+                ps[i], ms[i], vs[i] = adamw_step_fp32(ps[i], g, ms[i], vs[i], step + 1, cur_lr, eps=eps, wd=wd)
+            else:
+                ps[i] = sgd_step_fp32(ps[i], g, cur_lr, wd)
+        losses.append(loss.item())
+        trace.append([p.clone() for p in ps])
+    return losses, trace, gtrace
+
+
+# ---- run_norm_tune_tta.py:74-98: which norm parameters are unfrozen, in optimizer order (names of dit_oracle.make_params)
+def norm_param_names(depth: int, norm_target: str) -> List[str]:
+    if norm_target not in ("cross_attn_norm", "qk_norm", "all_norm"):
+        raise ValueError(f"Unknown norm_target: {norm_target}")
+    names = []
+    for i in range(depth):
+        b = f"blocks.{i}."
+        if norm_target in ("cross_attn_norm", "all_norm"):
+            names += [b + "pre_crs_attn_norm.weight", b + "pre_crs_attn_norm.bias"]
+        if norm_target in ("qk_norm", "all_norm"):
+            names += [b + "attn.q_norm.weight", b + "attn.k_norm.weight", b + "cross_attn.q_norm.weight", b + "cross_attn.k_norm.weight"]
+    return names
+
+
+# ---- run_lora_tta.py:286-382: adapter order = optimizer order: per block attn.qkv, attn.proj, then cross_attn.q_linear,
+#      cross_attn.kv_linear, cross_attn.proj (each when "qkv"/"proj" is targeted), then ffn.w1/w2/w3 with target_ffn
+def lora_target_names(depth: int, target_modules=("qkv", "proj"), target_ffn: bool = False, target_blocks: str = "all") -> List[str]:
+    active = parse_target_blocks(target_blocks, depth)
+    names = []
+    for i in range(depth):
+        if active is not None and i not in active:
+            continue
+        b = f"blocks.{i}."
+        if "qkv" in target_modules:
+            names.append(b + "attn.qkv")
+        if "proj" in target_modules:
+            names.append(b + "attn.proj")
+        if "qkv" in target_modules:
+            names += [b + "cross_attn.q_linear", b + "cross_attn.kv_linear"]
+        if "proj" in target_modules:
+            names.append(b + "cross_attn.proj")
+        if target_ffn:
+            names += [b + "ffn.w1", b + "ffn.w2", b + "ffn.w3"]
+    return names

@@ -1,0 +1,20 @@
+"""For rocprofv3 --pmc (round 4): the K3 projection shapes at M = 93 600 on the default 8-phase kernel, the four-wave stream
+kernel and hipBLASLt (torch), a few launches each.  argv: shape name (proj|qkv|w13|w2)."""
+import os, sys, torch
+sys.path.insert(0, "longcat-video-tta_amd"); sys.path.insert(0, ".")
+from lcv_hip import ops
+dev = "cuda"; bf = torch.bfloat16
+SH = {"proj": (4096, 4096), "qkv": (12288, 4096), "w13": (22016, 4096), "w2": (4096, 11008)}
+name = sys.argv[1] if len(sys.argv) > 1 else "proj"
+N, K = SH[name]
+M = 93600
+a = torch.randn(M, K, device=dev).to(bf); w = (torch.randn(N, K, device=dev) * 0.02).to(bf); b = torch.randn(N, device=dev).to(bf)
+for tile in ("9", "4"):
+    os.environ["LCV_GEMM_TILE"] = tile
+    for _ in range(6):
+        ops.gemm_nt(a, w, b)
+os.environ.pop("LCV_GEMM_TILE")
+for _ in range(6):
+    torch.nn.functional.linear(a, w, b)
+torch.cuda.synchronize()
+print("done")

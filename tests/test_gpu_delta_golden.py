@@ -1,0 +1,264 @@
+"""GPU: the PRODUCT's delta-A/B/C, FiLM, norm-tune wrappers and its LoRA / full-model batch loops (tta/delta.py,
+tta/inner_loop.py, tta/full_tta.py over the HIP DiT, through the C ABI) against fixtures minted from the REFERENCE's own classes
+and loops (tests/golden/make_delta_golden.py; reference: run_delta_{a,b,c}.py, run_film_tta.py, run_norm_tune_tta.py,
+run_lora_tta.py:558-634, run_full_tta.py:95-304).
+
+The fixtures are fp32; the product computes in bf16.  Criterion (the one the denoise- and backward-parity files use): the product
+may be as far from the fp32 reference result as the ORACLE IN BF16 MODE is — `err_hip < 1.5 * err_oracle_bf16 + floor` — with the
+bf16 oracle evaluated right here on the CPU for the same case.  Structure (parameter order and shapes, returned keys, which
+forward carries `delta_final`, constructor errors) is exact.
+"""
+import pytest
+import torch
+
+from conftest import rel_l2
+from delta_cases import (C, CFG, CT, DEPTH, I, J, NORM_CASES, P, T, WRAPPER_CASES, _forward_kw, _inputs, _loss, norm_case,
+                         norm_forward_kw)
+from oracle import dit_oracle as orc, tta_oracle as O
+
+pytestmark = pytest.mark.gpu
+BF16 = torch.bfloat16
+DEV = "cuda"
+
+
+def _dit():
+    from longcat_video.modules.longcat_video_dit import LongCatVideoTransformer3DModel
+    kw = T["cfg_kw"]
+    m = LongCatVideoTransformer3DModel(device=DEV, dtype=BF16, hidden_size=kw["hidden_size"], depth=kw["depth"],
+                                       num_heads=kw["num_heads"], caption_channels=kw["caption_channels"], adaln_tembed_dim=CT)
+    m.load_state_dict(orc.make_params(CFG, seed=T["weight_seed"], std=T["weight_std"]), strict=False)
+    return m
+
+
+class _Inject:
+    """sigma / noise draw k of the fixture for the product's loss (it calls torch.rand / torch.randn_like like the reference)."""
+
+    def __init__(self):
+        self.i = 0
+
+    def __enter__(self):
+        self._rand, self._randn_like = torch.rand, torch.randn_like
+        torch.rand = lambda *a, **k: I["sig_u"][self.i % 4].to(DEV).clone()
+
+        def randn_like(t, **k):
+            e = I["eps"][self.i % 4].to(DEV).clone()
+            self.i += 1
+            return e
+        torch.randn_like = randn_like
+        return self
+
+    def __exit__(self, *a):
+        torch.rand, torch.randn_like = self._rand, self._randn_like
+
+
+def _make(name, dit):
+    from tta import delta as D
+    if name == "delta_a":
+        return D.DeltaAWrapper(dit, adaln_tembed_dim=CT), (lambda w: [w.delta]), D.optimize_delta_a
+    if name.startswith("delta_b"):
+        w = D.DeltaBWrapper(dit, adaln_tembed_dim=CT, hidden_size=C, **J[name]["kw"])
+        assert list(w.block_to_group) == J[name]["block_to_group"]
+        assert (None if w.target_block_indices is None else sorted(w.target_block_indices)) == J[name]["target_block_indices"]
+        return w, (lambda w: list(w.deltas) + ([w.delta_final] if w.delta_final is not None else [])), D.optimize_delta_b
+    if name == "delta_c":
+        w = D.DeltaCWrapper(dit, "per_channel", CFG["out_channels"])          # the reference's positional order
+        assert w.mode == J[name]["mode"]
+        return w, (lambda w: [w.delta_out]), D.optimize_delta_c
+    mode = name[len("film_"):name.rfind("_g")]
+    w = D.FiLMAdapterWrapper(dit, num_groups=len(T[name]["init"]), hidden_size=C, film_mode=mode)
+    assert [w._get_group_idx(i) for i in range(w.num_blocks)] == J[name]["group_idx"] and w.correction_dim == J[name]["correction_dim"]
+    return w, (lambda w: list(w.corrections)), D.optimize_film_adapter
+
+
+def _check_forward_and_grads(name, case, w, params, fw_kw):
+    hs, ts, ncond, emb, mask, _, _ = _inputs(0)
+    args = (hs.to(DEV), ts.to(DEV), emb.to(DEV), mask.to(DEV))
+    with torch.no_grad():
+        for p, v in zip(params, case["init"]):
+            p.copy_(v)
+    w.eval()
+    with torch.no_grad():
+        hip_train = w(*args, num_cond_latents=ncond).float().cpu()
+        w.apply_to_dit()
+        hip_gen = w.dit(*args, num_cond_latents=ncond).float().cpu()
+        w.remove_from_dit()
+        hip_plain = w.dit(*args, num_cond_latents=ncond).float().cpu()
+        kw_t, kw_g = fw_kw(case["init"], True), fw_kw(case["init"], False)
+        o_train = orc.dit_forward(kw_t.pop("params", P), CFG, hs, ts, emb, mask, ncond, bf16=True, **kw_t)
+        o_gen = orc.dit_forward(kw_g.pop("params", P), CFG, hs, ts, emb, mask, ncond, bf16=True, **kw_g)
+    rec = {}
+    for tag, hip, orb, fix in (("train", hip_train, o_train, case["pred_train"]), ("gen", hip_gen, o_gen, case["pred_gen"])):
+        e_hip, e_orc = rel_l2(hip, fix), rel_l2(orb, fix)
+        rec[tag] = (e_hip, e_orc)
+        assert e_hip < 1.5 * e_orc + 1e-3, (name, tag, e_hip, e_orc)
+    if not name.startswith("norm_"):
+        # the adapter's own contribution (train - plain), as a fraction of the prediction: right place, right size
+        eff_fix = case["pred_train"] - case["pred_plain"]
+        eff_err = (torch.linalg.vector_norm((hip_train - hip_plain) - eff_fix) / torch.linalg.vector_norm(case["pred_train"])).item()
+        eff = rel_l2(case["pred_train"], case["pred_plain"])
+        rec["effect"] = (eff_err, eff)
+        assert eff_err < 0.5 * eff, (name, eff_err, eff)
+        if "delta_b_h" in name:   # generation leaves delta_final out (run_delta_b.py:175-212): the product's two forwards differ too
+            assert rel_l2(hip_gen, hip_train) > 1e-3
+    # gradients of one conditioned loss at this adapter state
+    from tta.flow_matching import compute_flow_matching_loss_conditioned
+    w.train()
+    for p in params:
+        p.grad = None
+    with _Inject():
+        loss = compute_flow_matching_loss_conditioned(dit=w, cond_latents=I["cond"].to(DEV), target_latents=I["train"].to(DEV),
+                                                      prompt_embeds=I["embeds"].to(DEV), prompt_mask=I["mask"].to(DEV),
+                                                      device=DEV, dtype=BF16)
+    loss.backward()
+    leaves = [p.clone().requires_grad_(True) for p in case["init"]]
+    o_loss, _ = _loss(0, bf16=True, **fw_kw(leaves, True))
+    o_grads = torch.autograd.grad(o_loss, leaves, allow_unused=True)
+    assert abs(loss.item() - float(case["loss"])) < 1.5 * abs(o_loss.item() - float(case["loss"])) + 2e-3 * float(case["loss"])
+    worst = 0.0
+    for p, og, fix in zip(params, o_grads, case["grads"]):
+        assert (p.grad is None) == (fix is None)
+        if fix is None:
+            continue
+        e_hip, e_orc = rel_l2(p.grad, fix), rel_l2(og, fix)
+        worst = max(worst, e_hip)
+        assert e_hip < 1.5 * e_orc + 1e-2, (name, e_hip, e_orc)
+    rec["grad_worst"] = worst
+    print(name, {k: tuple(round(x, 5) for x in v) if isinstance(v, tuple) else round(v, 5) for k, v in rec.items()})
+
+
+def _check_three_steps(name, case, res, params, loss_fn_bf16, start, per_param_clip=False):
+    losses, trace, _ = O.adapt_steps(loss_fn_bf16, start, T["steps"], T["lr"], per_param_clip=per_param_clip)
+    got, fix = torch.tensor(res["losses"]), case["losses"]
+    e_orc = (torch.tensor(losses) - fix).abs().max().item()
+    assert (got - fix).abs().max().item() < 1.5 * e_orc + 5e-3 * fix.abs().max().item(), (got, fix)
+    for p, ob, f in zip(params, trace[-1], case["final"]):
+        # Adam's first steps are sign-like, so an element whose gradient is below the bf16 noise may flip: both runs are held to
+        # the fp32 reference trajectory the same way
+        e_hip, e_o = rel_l2(p, f), rel_l2(ob, f)
+        assert e_hip < 1.5 * e_o + 0.05, (name, e_hip, e_o)
+
+
+@pytest.mark.parametrize("name", WRAPPER_CASES)
+def test_product_wrapper_vs_reference_fixture(name):
+    case = T[name]
+    dit = _dit()
+    w, params_of, optimise = _make(name, dit)
+    w = w.to(DEV)
+    params = params_of(w)
+    assert [list(p.shape) for p in params] == J[name]["param_shapes"]
+    _check_forward_and_grads(name, case, w, params, lambda ps, training: _forward_kw(name, ps, training))
+    # three steps of the product's loop from the reference's initial state (zeros)
+    dit2 = _dit()
+    w2, params_of, optimise = _make(name, dit2)
+    w2 = w2.to(DEV)
+    with _Inject():
+        res = optimise(w2, I["cond"].to(DEV), I["train"].to(DEV), I["embeds"].to(DEV), I["mask"].to(DEV), num_steps=T["steps"],
+                       lr=T["lr"], device=DEV, dtype=BF16)
+    assert set(res) >= set(J[name]["return_keys"]), (sorted(res), J[name]["return_keys"])
+    if name.startswith("delta_b"):
+        assert len(res["delta_norms"]) == len(case["ret_delta_norms"])
+    zeros = [torch.zeros_like(p) for p in case["init"]]
+    _check_three_steps(name, case, res, params_of(w2), lambda step, ps: _loss(step, bf16=True, **_forward_kw(name, ps, True))[0],
+                       zeros, per_param_clip=name.startswith("delta_b"))
+
+
+def test_constructor_errors_match_the_reference():
+    from tta import delta as D
+    dit = _dit()
+    assert J["delta_b_hidden_without_dim"] == "ERR:TypeError"
+    with pytest.raises(TypeError):
+        D.DeltaBWrapper(dit, delta_target="hidden", delta_dim=None)
+    assert J["delta_c_unknown_mode"] == "ERR:ValueError"
+    with pytest.raises(ValueError):
+        D.DeltaCWrapper(dit, "full", 16)
+
+
+@pytest.mark.parametrize("name", NORM_CASES)
+def test_product_norm_tuning_vs_reference_fixture(name):
+    from tta import delta as D
+    case = T[name]
+    target, also, names = norm_case(name)
+    dit = _dit()
+    w = D.NormTuneForward(dit, target, also_tune_delta=also).to(DEV)
+    params = w.tuned_params
+    assert [list(p.shape) for p in params] == J[name]["param_shapes"]
+    sd = dict(dit.named_parameters())
+    assert all(p is sd[n] for p, n in zip(params, names))         # the reference's optimizer order (run_norm_tune_tta.py:74-98)
+    _check_forward_and_grads(name, case, w, params, lambda ps, training: norm_forward_kw(name, ps))
+    w.restore()
+    dit2 = _dit()
+    w2 = D.NormTuneForward(dit2, target, also_tune_delta=also).to(DEV)
+    with _Inject():
+        res = D.optimize_norm_params(w2, w2.tuned_params, I["cond"].to(DEV), I["train"].to(DEV), I["embeds"].to(DEV), I["mask"].to(DEV),
+                                     num_steps=T["steps"], lr=T["lr"], device=DEV, dtype=BF16)
+    assert set(res) >= set(J[name]["return_keys"])
+    start = [P[n].clone() for n in names] + ([torch.zeros(CT)] if also else [])
+    _check_three_steps(name, case, res, w2.tuned_params, lambda step, ps: _loss(step, bf16=True, **norm_forward_kw(name, ps))[0], start)
+
+
+def _batch():
+    mk = lambda c, t, e, m: dict(cond_latents=I[c], train_latents=I[t], prompt_embeds=I[e], prompt_mask=I[m])   # host tensors,
+    return [mk("cond", "train", "embeds", "mask"), mk("cond2", "train2", "embeds2", "mask2")]                    # moved per step
+
+
+def test_product_lora_batch_loop_vs_reference_fixture():
+    """finetune_lora_batch (run_lora_tta.py:558-634): two videos round-robin, bf16 adapters (the reference casts them to the
+    module dtype, :332) against the reference's fp32-adapter run over the fp32 oracle DiT."""
+    from tta.inner_loop import finetune_lora_batch
+    from tta.lora import get_lora_parameters, inject_lora_into_dit
+    case, hp = T["lora_batch"], J["lora_batch"]["hp"]
+    dit = _dit()
+    for p in dit.parameters():
+        p.requires_grad = False
+    mods = inject_lora_into_dit(dit, rank=hp["rank"], alpha=hp["alpha"], target_modules=["qkv", "proj"], target_ffn=False,
+                                target_blocks="all")
+    params = get_lora_parameters(mods)
+    assert len(mods) == J["lora_batch"]["n_modules"] and [list(p.shape) for p in params] == J["lora_batch"]["param_shapes"]
+    with torch.no_grad():
+        for p, v in zip(params, case["init"]):
+            p.copy_(v)
+    with _Inject():
+        res = finetune_lora_batch(dit, mods, _batch(), num_steps=hp["num_steps"], lr=hp["lr"], warmup_steps=hp["warmup_steps"],
+                                  weight_decay=hp["weight_decay"], max_grad_norm=hp["max_grad_norm"], device=DEV, dtype=BF16)
+    assert sorted(res) == J["lora_batch"]["return_keys"]
+    got, fix = torch.tensor(res["losses"]), case["losses"]
+    print("lora batch losses", got.tolist(), fix.tolist())
+    assert torch.allclose(got, fix, rtol=2e-2)
+    # the second video is really visited: its losses differ from a one-video run's (steps 1 and 3 use video 2)
+    errs = [rel_l2(p, f) for p, f in zip(params, case["final"])]
+    print("lora batch final adapters rel-L2 max / median:", max(errs), sorted(errs)[len(errs) // 2])
+    assert max(errs) < 0.12 and sorted(errs)[len(errs) // 2] < 0.06    # bf16 adapters + Adam's sign-like first steps (see test_gpu_backward)
+
+
+@pytest.mark.parametrize("name,opt,lr,batch", [("full_single_sgd", "sgd", 1e-3, False), ("full_batch_sgd", "sgd", 1e-3, True),
+                                               ("full_batch_adamw", "adamw", 1e-4, True)])
+def test_product_full_model_loops_vs_reference_fixture(name, opt, lr, batch):
+    from tta.full_tta import finetune_full_batch, finetune_full_on_conditioning
+    case = T[name]
+    dit = _dit()
+    for p in dit.parameters():
+        p.requires_grad = True
+    base = {n: p.detach().float().clone() for n, p in dit.named_parameters()}
+    with _Inject():
+        if batch:
+            res = finetune_full_batch(dit, _batch(), num_steps=3, lr=lr, warmup_steps=2, weight_decay=0.01, max_grad_norm=1.0,
+                                      device=DEV, dtype=BF16, optimizer_type=opt)
+        else:
+            res = finetune_full_on_conditioning(dit, I["cond"].to(DEV), I["train"].to(DEV), I["embeds"].to(DEV), I["mask"].to(DEV),
+                                                num_steps=3, lr=lr, warmup_steps=2, weight_decay=0.01, max_grad_norm=1.0,
+                                                device=DEV, dtype=BF16, optimizer_type=opt)
+    assert sorted(res) == J[name]["return_keys"]
+    got, fix = torch.tensor(res["losses"]), case["losses"]
+    print(name, "losses", got.tolist(), fix.tolist())
+    assert torch.allclose(got, fix, rtol=2e-2)
+    # how far each parameter moved.  The bf16 weights cannot resolve these steps (lr * g ~ 1e-6 against a bf16 ulp of 2e-4 on a
+    # 0.05-sized weight: the reference trains bf16 weights too and loses them the same way), so the comparison is on the
+    # parameters the product keeps in fp32 (the adaLN / timestep-embedder islands): norm of the change and its first elements
+    errs = []
+    for n, p in dit.named_parameters():
+        if p.dtype != torch.float32 or case["change"][n][0].item() == 0.0:
+            continue
+        d = p.detach().float().cpu() - base[n].cpu()
+        errs.append(rel_l2(torch.cat([d.norm().view(1), d.flatten()[:8]]), case["change"][n]))
+    print(name, "fp32 tensors compared:", len(errs), "worst / median summary rel-L2:", max(errs), sorted(errs)[len(errs) // 2])
+    assert len(errs) >= DEPTH and sorted(errs)[len(errs) // 2] < (0.25 if opt == "adamw" else 0.08) and max(errs) < 0.6

@@ -122,8 +122,8 @@ def test_cached_conditioning_anchor_form_equals_the_full_sequence_batch(monkeypa
     worst = {"dit": w0, "lora": w1}
     Ct, C = dit.config.adaln_tembed_dim, dit.config.hidden_size
     for name, w in (("delta_a", DeltaAWrapper(dit, adaln_tembed_dim=Ct)),
-                    ("delta_b_hidden", DeltaBWrapper(dit, num_groups=2, adaln_tembed_dim=Ct, hidden_size=C, delta_target="hidden")),
-                    ("delta_c", DeltaCWrapper(dit, out_channels=16)),
+                    ("delta_b_hidden", DeltaBWrapper(dit, num_groups=2, adaln_tembed_dim=Ct, hidden_size=C, delta_target="hidden", delta_dim=C)),
+                    ("delta_c", DeltaCWrapper(dit, "per_channel", 16)),
                     ("film", FiLMAdapterWrapper(dit, num_groups=2, hidden_size=C, film_mode="full"))):
         w = w.to(DEV).eval()
         with torch.no_grad():

@@ -92,7 +92,7 @@ def _run(rel, argv):
 @pytest.mark.parametrize("rel,method,extra,key", [
     ("delta_experiment/scripts/run_delta_a.py", "delta_a", ["--delta-steps", "4", "--delta-lr", "1e-2"], "delta_norm"),
     ("delta_experiment/scripts/run_delta_b.py", "delta_b", ["--delta-steps", "4", "--delta-lr", "1e-2", "--num-groups", "2"], "delta_norms"),
-    ("delta_experiment/scripts/run_delta_c.py", "delta_c", ["--delta-steps", "4", "--delta-lr", "1e-2"], "delta_norm"),
+    ("delta_experiment/scripts/run_delta_c.py", "delta_c", ["--delta-steps", "4", "--delta-lr", "1e-2"], "delta_out_norm"),
     ("delta_experiment/scripts/run_film_tta.py", "film_adapter", ["--film-steps", "4", "--film-lr", "1e-2", "--num-groups", "2",
                                                                   "--film-mode", "shift_scale"], "correction_norm"),
     ("delta_experiment/scripts/run_norm_tune_tta.py", "norm_tune", ["--norm-steps", "4", "--norm-lr", "1e-2", "--norm-target",

@@ -1,5 +1,5 @@
 """Raw per-kernel means of every counter found under the rocprofv3 output directories given (one line per directory and kernel),
-with the kernel's mean duration from the kernel trace.  Usage: python tools/pmc_raw.py DIR [DIR ...] [--match substring]"""
+with the kernel's mean duration from the kernel trace.  Usage: python tools/pmc_raw.py DIR [DIR ...] [--match substring[,substring...]]"""
 import csv
 import glob
 import os
@@ -19,7 +19,7 @@ for d in args:
         for r in csv.DictReader(open(f)):
             times[r["Kernel_Name"][:60]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
     for k in sorted(vals):
-        if match not in k:
+        if match and not any(m in k for m in match.split(",")):
             continue
         ms = sum(times[k]) / max(1, len(times[k]))
         print(f"{d} | {k} | {ms:.3f} ms x{len(times[k])} | " + ", ".join(f"{c}={sum(x) / len(x):.4g}" for c, x in sorted(vals[k].items())))
