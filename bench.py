@@ -59,6 +59,8 @@ def parse():
     ap.add_argument("--full-tta-leg", action="store_true",
                     help="also time full-model TTA at the 480p operating point (SURVEY §2.1 #9 marks it out of scope: opt-in since round 3)")
     ap.add_argument("--no-k3p", action="store_true", help="skip the one secondary CFG step at the literal 49x90x160 size (~45 s)")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="with --gpus N > 1 and no torch.distributed environment: print the launcher command and exit")
     ap.add_argument("--parallelism", default="dp", choices=["dp", "sp"],
                     help="dp: one independent video per GPU (weak scaling, default); sp: ONE video, latent frames sharded "
                          "over the GPUs with an RCCL K/V all-gather per attention layer (strong scaling, config K5)")
@@ -301,14 +303,37 @@ def measure_extras(dit, dev, T, h, w, pe, pm) -> dict:
     return out
 
 
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` with no torch.distributed environment: start N ranks of this same file under
+    torch.distributed.run (one process per GPU over RCCL) as a CHILD process, relay its output — rank 0 prints the one JSON
+    line — and return its exit code.  This process never touches the GPU (importing torch does not initialise it), and nothing
+    that has is ever replaced by another program."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    passthrough = [a for a in sys.argv[1:] if a != "--dry-launch"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()), *passthrough]
+    if args.dry_launch:
+        print(" ".join(cmd), flush=True)
+        return 0
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this pool's host driver
+    progress(f"no torch.distributed environment: launching {args.gpus} ranks: {' '.join(cmd)}")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(launch_ranks(args))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU")
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -372,19 +397,23 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     prof, ops.PROFILE = ops.PROFILE, None
+    rccl_ranks = 1
     if dist is not None:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = tmax.item()
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)                      # the group size as a real RCCL all-reduce sees it
+        rccl_ranks = int(ones.item())
     assert torch.isfinite(x).all().item(), "non-finite latents"
 
     sec_per_step = elapsed / args.steps
     progress(f"timed region done: {sec_per_step:.3f} s per step")
 
-    # ---- secondary timings (untimed region): one CFG denoise step at BASELINE configs 2 and 1 (K2 49x480p, K1 16x256x256) ----
+    # ---- secondary timings (untimed region): one CFG denoise step at BASELINE configs 2, 1 and 5 (K2 49x480p, K1 16x256x256, K5 121x480p) ----
     secondary = {}
     if world == 1 and not args.no_extras and args.workload == "K3":
-        for name in ("K2", "K1"):
+        for name in ("K2", "K1", "K5"):     # BASELINE.json configs 2, 1 and 5 (the 121-frame clip, on one GPU)
             T2, h2, w2, _ = WORKLOADS[name]
             lat2 = torch.randn((1, 16, T2, h2, w2), generator=g, device=dev, dtype=torch.float32)
             run2 = lambda a, b_, x_: pipe.denoise(x_, pe, pm, ne, nm, num_cond_latents=0, num_inference_steps=args.num_inference_steps,
@@ -451,6 +480,7 @@ def main():
         "metric": "denoised latent frames/sec (49x720p, 50-step CFG denoise)", "value": value,
         "unit": "latent frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": sec_per_step * 1e3, "higher_is_better": True, "scaling": "strong" if sp else "weak", "vs_baseline": None,
+        "rccl_ranks": rccl_ranks,
         "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"{args.workload}: {desc}; DiT 48 blocks x 4096 hidden, CFG {args.guidance_scale}, "
                                f"{args.num_inference_steps}-step flow-match Euler, no conditioning frames",

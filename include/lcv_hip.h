@@ -148,7 +148,8 @@ const char* lcv_attn_fwd_last_kernel(void);
  * csrc/attn_bwd.hip).  d_o shares o's strides.  delta_ws: fp32 workspace of lcv_attn_bwd_ws_floats(B, H, Nq, Nk) floats:
  * B*H*(Nq + 2*roundup(Nq, 32)) (delta, then the padded -lse*log2(e) / -delta rows the second-form pass A streams into LDS),
  * plus qsplit*B*H*Nk*256 when the query sweep of a short-key call (Nk <= 128: the 77-key text cross-attention) is split over
- * workgroups - one fp32 dK / dV slice per split, added in split order by a finishing kernel.  accumulate_kv != 0 adds into the
+ * workgroups - one fp32 dK / dV slice per split, added in split order by a finishing kernel (the size is an UPPER bound: the
+ * slices are counted for every call of such sizes, also the unit-scale ones whose pass A does not use them).  accumulate_kv != 0 adds into the
  * existing dk/dv (second region of the conditioning split).  dq/dk/dv are addressed like q/k/v with their own strides. */
 int64_t lcv_attn_bwd_ws_floats(int64_t B, int64_t H, int64_t Nq, int64_t Nk);   /* host-only; a size, not a status */
 int lcv_attn_bwd(const void* q, const void* k, const void* v, const void* o,

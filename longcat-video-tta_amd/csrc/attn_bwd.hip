@@ -516,7 +516,6 @@ static int attn_bwd_qsplit(int64_t B, int64_t H, int64_t Nq, int64_t Nk) {
   return qsplit < 1 ? 1 : qsplit;
 }
 
-// floats of `delta_ws` a call of lcv_attn_bwd with these sizes needs (host-only; a size, not a status)
 // pass A, third form (attn_bwd_dkv3.hip, round 3): 256 keys per workgroup, one wave per SIMD, software-pipelined
 int attn_bwd_dkv3_launch(const void* q, const void* k, const void* v, const void* d_o, const float* consts,
                          void* dk, void* dv, int accumulate_kv, int64_t B, int64_t H, int64_t Nq, int64_t Nk, int64_t q_sb,
@@ -524,6 +523,10 @@ int attn_bwd_dkv3_launch(const void* q, const void* k, const void* v, const void
                          int64_t v_sh, int64_t o_sb, int64_t o_sn, int64_t o_sh, int64_t dk_sb, int64_t dk_sn, int64_t dk_sh,
                          int64_t dv_sb, int64_t dv_sn, int64_t dv_sh, float scale, hipStream_t s);
 
+// floats of `delta_ws` a call of lcv_attn_bwd with these sizes needs (host-only; a size, not a status).  An UPPER bound: the
+// per-split dK / dV slices (`qs` x B x H x Nk x 256 floats) are counted whenever the query sweep of these sizes would be split,
+// although a unit-scale call that takes the second / third-form pass A does not touch them (only few-key shapes split: <= 128
+// keys, so the term is at most 64 x B x H x 128 x 256 floats).
 extern "C" int64_t lcv_attn_bwd_ws_floats(int64_t B, int64_t H, int64_t Nq, int64_t Nk) {
   if (B <= 0 || H <= 0 || Nq < 0 || Nk <= 0) return 0;
   int64_t n = B * H * (Nq + 2 * ((Nq + 31) / 32 * 32));

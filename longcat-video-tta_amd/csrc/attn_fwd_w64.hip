@@ -563,7 +563,8 @@ __global__ __launch_bounds__(256) void attn_fwd_w64_kernel(const AttnFwdW64Param
   }
 }
 
-// called by lcv_attn_fwd (attn_fwd.hip) under LCV_ATTN_FWD_W64=1 for unit-scale self-attention with Nk > 512
+// called by lcv_attn_fwd (attn_fwd.hip) for unit-scale self-attention with Nk > 512: the default since round 3 (LCV_ATTN_FWD_W64=0
+// selects attn_fwd_pipe.hip instead)
 int attn_fwd_w64_launch(const void* q, const void* k, const void* v, void* o, float* lse, int64_t B, int64_t H, int64_t Nq,
                         int64_t Nk, int64_t q_sb, int64_t q_sn, int64_t q_sh, int64_t k_sb, int64_t k_sn, int64_t k_sh,
                         int64_t v_sb, int64_t v_sn, int64_t v_sh, int64_t o_sb, int64_t o_sn, int64_t o_sh, float scale,

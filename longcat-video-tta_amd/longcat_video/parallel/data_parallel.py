@@ -52,7 +52,7 @@ def host_group():
 
 
 LAST_MERGE_MISSING: List[int] = []      # ranks whose final rows rank 0 did not get in time (filled by gather_results)
-_JOB_START = {}
+_JOB_NONCE = {}                         # output directory -> the identity of THIS job (rank 0 draws it, every rank holds it)
 
 
 def _deposit_path(output_dir: str, rank: int) -> str:
@@ -60,14 +60,21 @@ def _deposit_path(output_dir: str, rank: int) -> str:
 
 
 def begin_job(output_dir: str, rank: int) -> None:
-    """Call once per rank right after the output directory exists: clears this rank's end-of-job deposit of an earlier run
-    in the same directory (a resumed job) and notes when this job started."""
-    import time
-    _JOB_START[os.path.abspath(output_dir)] = time.time()
+    """Call once per rank right after the output directory exists (collective at world size > 1: every rank calls it, at
+    start-up, when all of them are alive): clears this rank's end-of-job deposit of an earlier run in the same directory (a
+    resumed job) and agrees on a job nonce — rank 0 draws it, the host group broadcasts it.  Deposits carry the nonce, so
+    rank 0 recognises a leftover of an earlier job by CONTENT; file times are never compared (on a shared file system they
+    come from another host's clock)."""
+    import uuid
+    import torch.distributed as dist
     try:
         os.remove(_deposit_path(output_dir, rank))
     except FileNotFoundError:
         pass
+    box = [uuid.uuid4().hex]
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast_object_list(box, src=0, group=host_group() if dist.get_backend() != "gloo" else None)
+    _JOB_NONCE[os.path.abspath(output_dir)] = box[0]
 
 
 def merge_wait_seconds(per_video_s: float = 0.0, videos_per_rank: int = 1) -> float:
@@ -106,21 +113,24 @@ def gather_results(local_rows: List[Dict[str, Any]], group=None, output_dir: Opt
     rank, world = dist.get_rank(), dist.get_world_size()
     tmp = _deposit_path(output_dir, rank) + ".tmp"
     with open(tmp, "w") as f:
-        json.dump({"finished": True, "rank": rank, "results": local_rows}, f, default=str)
+        json.dump({"finished": True, "rank": rank, "job": _JOB_NONCE.get(os.path.abspath(output_dir)), "results": local_rows}, f,
+                  default=str)
     os.replace(tmp, _deposit_path(output_dir, rank))
     if rank != 0:
         return None
-    started = _JOB_START.get(os.path.abspath(output_dir), 0.0)
+    job = _JOB_NONCE.get(os.path.abspath(output_dir))
     deadline = time.time() + (merge_wait_seconds() if wait_s is None else float(wait_s))
     per_rank: Dict[int, List[Dict[str, Any]]] = {0: local_rows}
     while True:
         for r in range(1, world):
             p = _deposit_path(output_dir, r)
-            if r in per_rank or not os.path.exists(p) or os.path.getmtime(p) < started - 60.0:
-                continue                                 # not there yet, or a leftover of an earlier job in this directory
+            if r in per_rank or not os.path.exists(p):
+                continue
             try:
                 with open(p) as f:
-                    per_rank[r] = json.load(f)["results"]
+                    dep = json.load(f)
+                if dep.get("job") == job:                # else: a leftover of an earlier job in this directory
+                    per_rank[r] = dep["results"]
             except (OSError, ValueError, KeyError):
                 pass                                     # caught mid-replace on a network file system: next poll
         if len(per_rank) == world or time.time() >= deadline:

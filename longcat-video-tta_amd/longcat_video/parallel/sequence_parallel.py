@@ -68,17 +68,55 @@ def _pad_rows(x: torch.Tensor, n_max: int) -> torch.Tensor:
     return out
 
 
-_COALESCE = {"ok": None}      # None = untried; the RCCL backend groups several tensor collectives into one launch, gloo cannot
+def probe_grouped_collectives(group=None, device=None) -> bool:
+    """Can this torch / backend put several tensor collectives into ONE launch (`dist._coalescing_manager`, a private API)?
+    Asked ONCE per SPContext, outside the data path, by every rank: a tiny grouped all-gather, with only the errors a missing or
+    re-shaped API raises (AttributeError / TypeError) read as "no"; the verdict is then all-reduced (MIN) so that every rank takes
+    the same branch for the rest of the job.  A RuntimeError from a real collective is NOT caught, here or in the data path: a
+    rank that fell back alone would issue a different collective sequence from its peers and the job would hang instead of
+    failing."""
+    import torch.distributed as dist
+    if dist.get_backend(group) != "nccl" or os.environ.get("LCV_SP_COALESCE", "1") != "1":
+        return False
+    device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    world = dist.get_world_size(group)
+    ok = 1
+    try:
+        ins = [torch.full((4,), float(dist.get_rank(group)), device=device) for _ in range(2)]
+        outs = [torch.empty(4 * world, device=device) for _ in range(2)]
+        with dist._coalescing_manager(group=group, device=device, async_ops=False):
+            for o, i in zip(outs, ins):
+                dist.all_gather_into_tensor(o, i, group=group)
+        if not all(torch.equal(o.view(world, 4)[:, 0].cpu(), torch.arange(world, dtype=torch.float32)) for o in outs):
+            ok = 0
+    except (AttributeError, TypeError) as ex:
+        print(f"  sequence parallel: grouped collectives unavailable in this torch ({type(ex).__name__}: {ex}); one launch per tensor")
+        ok = 0
+    verdict = torch.tensor([ok], device=device, dtype=torch.int32)
+    dist.all_reduce(verdict, op=dist.ReduceOp.MIN, group=group)
+    return bool(verdict.item())
 
 
-def _gather_many(xs: List[torch.Tensor], counts: List[int], S: int, group=None) -> List[torch.Tensor]:
+def _issue(calls, group, device, grouped: bool) -> None:
+    """Run the collective thunks, as one grouped launch when the backend can (decided once by `probe_grouped_collectives`)."""
+    import torch.distributed as dist
+    if grouped and len(calls) > 1:
+        with dist._coalescing_manager(group=group, device=device, async_ops=False):
+            for c in calls:
+                c()
+    else:
+        for c in calls:
+            c()
+
+
+def _gather_many(xs: List[torch.Tensor], counts: List[int], S: int, group=None, grouped: bool = False) -> List[torch.Tensor]:
     """All-gather several [B, n_local, ...] tensors along the token axis; each result is [B, N, ...] in sequence order (a
     VIEW of its padded [B, W * n_max, ...] buffer when the pads sit at the end, see `pads_at_end`).
 
-    K and V of BOTH CFG batch elements of a layer are exchanged as ONE grouped launch on RCCL (`_coalescing_manager`: one
-    ncclGroup around the 2 x B `all_gather_into_tensor` calls) - a batch element must land in its own [W * n_max] rows for the
-    attention kernel's (batch, token) strides, so the calls stay separate ops, but not separate launches.  Backends without
-    coalescing (gloo: the CPU tests, ranks sharing one GPU) issue them one after the other; same bytes, same result."""
+    K and V of BOTH CFG batch elements of a layer are exchanged as ONE grouped launch on RCCL (`grouped`: one ncclGroup around
+    the 2 x B `all_gather_into_tensor` calls) - a batch element must land in its own [W * n_max] rows for the attention kernel's
+    (batch, token) strides, so the calls stay separate ops, but not separate launches.  Backends without grouping (gloo: the CPU
+    tests, ranks sharing one GPU) issue them one after the other; same bytes, same result."""
     import torch.distributed as dist
     world = len(counts)
     n_max = max(counts) * S
@@ -94,39 +132,28 @@ def _gather_many(xs: List[torch.Tensor], counts: List[int], S: int, group=None) 
     pads = [_pad_rows(x, n_max) for x in xs]
     outs = [torch.empty((x.shape[0], world * n_max) + tuple(x.shape[2:]), dtype=x.dtype, device=x.device) for x in xs]
     pairs = [(o[b], xp[b]) for o, xp in zip(outs, pads) for b in range(xp.shape[0])]
-    want = (_COALESCE["ok"] is not False and len(pairs) > 1 and pads[0].is_cuda and dist.get_backend(group) == "nccl"
-            and os.environ.get("LCV_SP_COALESCE", "1") == "1")
-    done = False
-    if want:
-        try:
-            with dist._coalescing_manager(group=group, device=pads[0].device, async_ops=False):
-                for o, i in pairs:
-                    dist.all_gather_into_tensor(o, i, group=group)
-            _COALESCE["ok"] = done = True
-        except (RuntimeError, AttributeError, TypeError) as ex:   # an older / different backend: fall back for good, say so once
-            if _COALESCE["ok"] is None:
-                print(f"  sequence parallel: grouped K/V gather unavailable ({type(ex).__name__}: {ex}); using one collective per tensor")
-            _COALESCE["ok"] = False
-    if not done:
-        for o, i in pairs:
-            dist.all_gather_into_tensor(o, i, group=group)
+    _issue([lambda o=o, i=i: dist.all_gather_into_tensor(o, i, group=group) for o, i in pairs], group, pads[0].device,
+           grouped and pads[0].is_cuda)
     return [o[:, :N] for o in outs]
 
 
-def _gather_rows(x: torch.Tensor, counts: List[int], S: int, group=None, out: torch.Tensor = None) -> torch.Tensor:
+def _gather_rows(x: torch.Tensor, counts: List[int], S: int, group=None, out: torch.Tensor = None,
+                 grouped: bool = False) -> torch.Tensor:
     """All-gather ONE tensor along the token axis; returns [B, N, ...] in sequence order."""
-    return _gather_many([x], counts, S, group)[0]
+    return _gather_many([x], counts, S, group, grouped)[0]
 
 
 def all_gather_kv(k_local: torch.Tensor, v_local: torch.Tensor, counts: List[int], tokens_per_frame: int,
-                  group=None) -> Tuple[torch.Tensor, torch.Tensor]:
+                  group=None, grouped: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     """[B, n_local, H, D] shards -> full [B, N, H, D] K and V in sequence order (one grouped launch on RCCL)."""
-    k, v = _gather_many([k_local, v_local], counts, tokens_per_frame, group)
+    k, v = _gather_many([k_local, v_local], counts, tokens_per_frame, group, grouped)
     return k, v
 
 
-def reduce_scatter_kv_grad(d_full: torch.Tensor, counts: List[int], tokens_per_frame: int, group=None) -> torch.Tensor:
-    """Sum the full-length dK (or dV) [B, N, ...] over ranks and keep this rank's rows."""
+def reduce_scatter_kv_grad(d_full: torch.Tensor, counts: List[int], tokens_per_frame: int, group=None,
+                           grouped: bool = False) -> torch.Tensor:
+    """Sum the full-length dK (or dV) [B, N, ...] over ranks and keep this rank's rows (the batch elements' collectives as one
+    grouped launch on RCCL, like the forward's gather)."""
     import torch.distributed as dist
     rank = dist.get_rank(group)
     world = len(counts)
@@ -139,8 +166,8 @@ def reduce_scatter_kv_grad(d_full: torch.Tensor, counts: List[int], tokens_per_f
         if base is None:
             base = _pad_rows(d_full, world * n_max)
         out = torch.empty((B, n_max) + tuple(d_full.shape[2:]), dtype=d_full.dtype, device=d_full.device)
-        for b in range(B):
-            dist.reduce_scatter_tensor(out[b], base[b], op=dist.ReduceOp.SUM, group=group)
+        _issue([lambda b=b: dist.reduce_scatter_tensor(out[b], base[b], op=dist.ReduceOp.SUM, group=group) for b in range(B)],
+               group, d_full.device, grouped and d_full.is_cuda)
         return out[:, :n_loc].contiguous()
     d = d_full.contiguous().clone()                          # gaps inside the sequence: all-reduce + slice
     dist.all_reduce(d, op=dist.ReduceOp.SUM, group=group)
@@ -173,6 +200,11 @@ class SPContext:
         self.num_cond_frames = 0                                 # conditioning frames pinned in the sequence (set by the model)
         self._host_staged = dist.get_backend(group) == "gloo"
         self.overlap = os.environ.get("LCV_SP_OVERLAP", "0") == "1"
+        # one grouped launch per K/V exchange where the backend can: asked once here, by every rank, with one shared verdict
+        key = id(group)
+        if key not in SPContext._GROUPED:
+            SPContext._GROUPED[key] = probe_grouped_collectives(group)
+        self.grouped = SPContext._GROUPED[key]
 
     @property
     def grid(self):
@@ -185,6 +217,7 @@ class SPContext:
         return max(0, min(self.t1, int(n_frames) * self.rows_per_frame) - self.t0)
 
     _SIDE = {}
+    _GROUPED = {}          # id(process group) -> verdict of probe_grouped_collectives
 
     def side_stream(self, device) -> "torch.cuda.Stream":
         """One side stream per device for the K/V gather of the overlapped form.  It carries collectives only — no GEMM is
@@ -213,7 +246,7 @@ class SPContext:
         if self._host_staged and k_local.is_cuda:
             k, v = _gather_many([k_local.cpu(), v_local.cpu()], self.counts, self.S, self.group)
             return k.to(k_local.device), v.to(v_local.device)
-        k, v = _gather_many([k_local, v_local], self.counts, self.S, self.group)
+        k, v = _gather_many([k_local, v_local], self.counts, self.S, self.group, self.grouped)
         return k, v
 
     def padded_zeros(self, like: torch.Tensor) -> torch.Tensor:
@@ -229,7 +262,7 @@ class SPContext:
 
     def reduce_scatter_kv(self, d_full: torch.Tensor) -> torch.Tensor:
         """Adjoint of `all_gather_kv` for one tensor: sum the full-length gradient over ranks, keep this rank's rows."""
-        return self._coll(lambda t: reduce_scatter_kv_grad(t, self.counts, self.S, self.group), d_full)
+        return self._coll(lambda t: reduce_scatter_kv_grad(t, self.counts, self.S, self.group, self.grouped), d_full)
 
     def gather_frames_autograd(self, x_local: torch.Tensor) -> torch.Tensor:
         """`gather_frames` with a backward: every rank evaluates the SAME loss on the gathered prediction, so the gradient

@@ -48,6 +48,9 @@ def _worker(rank, world, port, tmp):
         dist.barrier()
         if rank == 1:
             dp.write_checkpoint(tmp, mine[0] + world, rows[:1], rank=rank)        # one video done, then it hangs
+            # ... and a deposit of an EARLIER job lies in the directory (a peer that died before begin_job could clear it): it
+            # carries another job's nonce and is recognised by content, whatever its file time says
+            Path(dp._deposit_path(tmp, 1)).write_text(json.dumps({"finished": True, "rank": 1, "job": "an-earlier-job", "results": rows}))
         dist.barrier()
         if rank == 0:
             import time
@@ -148,3 +151,67 @@ def test_world_size_2_gloo():
         ck = json.loads((Path(tmp) / "checkpoint.json").read_text())
         assert ck["next_idx"] == 7 and len(ck["results"]) == 7
         assert (Path(tmp) / "checkpoint.rank1.json").exists()
+
+
+def _worker_8(rank, world, port):
+    """8 ranks over gloo at the two sequence-parallel geometries of BASELINE.json (K3: 13 frames x 45 rows of 80 tokens; K5: 31
+    frames x 30 rows of 52 tokens), with 4 conditioning frames pinned in front (H x D shrunk to 1 x 4: the bookkeeping is what
+    is under test): shard sizes, global offsets, K/V gather of a CFG pair, the reduce-scatter adjoint, the conditioning rows
+    each rank holds, the row-wise gather of the prediction."""
+    sys.path.insert(0, str(ROOT / "longcat-video-tta_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from longcat_video.parallel import sequence_parallel as sp
+        for name, (T, rows, per_row, counts) in {"K3": (13, 45, 80, [74] * 7 + [67]), "K5": (31, 30, 52, [117] * 7 + [111])}.items():
+            ctx = sp.SPContext(T, rows * per_row, rows_per_frame=rows)
+            assert ctx.counts == counts and ctx.S == per_row and ctx.num_units == T * rows and ctx.grid == (T, rows, per_row)
+            assert not ctx.grouped                                         # gloo: one launch per tensor
+            assert ctx.token_offset == sum(counts[:rank]) * per_row and sp.pads_at_end(ctx.counts)
+            N = T * rows * per_row
+            g = torch.Generator().manual_seed(7)
+            full = torch.randn(2, N, 1, 4, generator=g)                    # the CFG pair, identical on every rank
+            lo, hi = ctx.token_offset, ctx.token_offset + counts[rank] * per_row
+            k, v = ctx.all_gather_kv(full[:, lo:hi].contiguous(), (full * 2.0)[:, lo:hi].contiguous())
+            assert k.shape == (2, N, 1, 4) and torch.equal(k, full) and torch.equal(v, full * 2.0)
+            assert k._base.shape[1] == world * counts[0] * per_row         # ONE padded buffer, pads at the end
+            d = ctx.padded_zeros(k)
+            d += float(rank + 1)
+            dl = ctx.reduce_scatter_kv(d)
+            assert dl.shape == (2, counts[rank] * per_row, 1, 4) and torch.all(dl == float(sum(range(1, world + 1))))
+            # 4 conditioning frames = the first 4 * rows units: a prefix of the sequence, split over the first ranks by rows
+            held = ctx.local_units_of_leading_frames(4)
+            tot = torch.tensor([held]); dist.all_reduce(tot)
+            assert tot.item() == 4 * rows
+            first = 4 * rows
+            assert held == max(0, min(ctx.t1, first) - ctx.t0) and (held == counts[rank] or ctx.t1 > first or held == 0 or ctx.t1 == first)
+            # the prediction returns by token rows of height 2
+            pred = torch.arange(T * rows * 2 * 3, dtype=torch.float32).view(1, 1, T * rows, 2, 3)
+            assert torch.equal(ctx.gather_frames(pred[:, :, ctx.t0:ctx.t1].contiguous()), pred)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world_size_8_gloo_k3_and_k5_geometries():
+    mp.spawn(_worker_8, args=(8, 31500 + os.getpid() % 2000), nprocs=8, join=True)
+
+
+def test_bench_launches_its_own_ranks_for_more_than_one_gpu():
+    """`python bench.py --gpus N` without a torch.distributed environment (the form the driver uses) starts N ranks under
+    torch.distributed.run as a child process; --dry-launch prints that command.  The parent never initialises the GPU."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1", "--dry-launch"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr
+    cmd = r.stdout.strip().split()
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    tail = cmd[cmd.index(str(ROOT / "bench.py")) + 1:]
+    assert tail == ["--gpus", "4", "--steps", "2", "--warmup", "1"]          # the ranks get the caller's flags, minus --dry-launch
+    # a mismatched environment is an error, not a silent single-GPU run
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                       env=dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"), timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
