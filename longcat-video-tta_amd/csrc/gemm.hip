@@ -351,7 +351,9 @@ typedef __attribute__((ext_vector_type(4))) float f32x4v;
 // ---- epilogue of the 16x16x32 kernels: acc[i][j][e] = C[m = mw + 16 i + (lane & 15)][n = nw + 16 j + 4 (lane >> 4) + e] ----
 // ROW_FENCE: a scheduling fence after every 16-row block, for kernels whose accumulators live in AGPRs - without it hipcc
 // hoists all TM x TN accumulator reads (and the address arithmetic of every store) to the top and spills around them.
-template <int TM, int TN, int EPI, bool ROW_FENCE = false>
+// PAIRED (gemm4k.h): the weight rows of a 32-column block are dealt to its two 16-row MFMA tiles so that a lane's 4 + 4 values of
+// tiles (2u, 2u + 1) are 8 CONSECUTIVE columns: acc[i][j][e] = C[m][n = nw + 32 (j >> 1) + 8 (lane >> 4) + 4 (j & 1) + e].
+template <int TM, int TN, int EPI, bool ROW_FENCE = false, bool PAIRED = false>
 __device__ __forceinline__ void gemm16_epilogue(const GemmParams& p, f32x4v (&acc)[TM][TN], int64_t mw, int64_t nw, int r16,
                                                 int q) {
   // ---- epilogue: lane owns row m and 4 consecutive columns per (i, j) ----
@@ -373,9 +375,10 @@ __device__ __forceinline__ void gemm16_epilogue(const GemmParams& p, f32x4v (&ac
       for (int jb = 0; jb < TN / 4; ++jb)
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-          const int64_t ng = nw + jb * 64 + 16 * u + 4 * q;
+          const int in_blk = PAIRED ? 8 * q + 4 * u : 16 * u + 4 * q;
+          const int64_t ng = nw + jb * 64 + in_blk;
           if (ng >= p.N) continue;
-          const int64_t f = (nw + jb * 64) / 2 + 16 * u + 4 * q;
+          const int64_t f = (nw + jb * 64) / 2 + in_blk;
           u16x4 o, og, ou;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -406,7 +409,7 @@ __device__ __forceinline__ void gemm16_epilogue(const GemmParams& p, f32x4v (&ac
     } else {
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const int64_t n = nw + j * 16 + 4 * q;
+        const int64_t n = nw + (PAIRED ? (j >> 1) * 32 + 8 * q + 4 * (j & 1) : j * 16 + 4 * q);
         if (n >= p.N) continue;
         const bool full = vec && (n + 3 < p.N);
         float v[4];
@@ -1140,6 +1143,7 @@ static int launch_conv8p(GemmParams& p, hipStream_t s) {
 
 #include "gemm4w.h"
 #include "gemm4p.h"
+#include "gemm4k.h"
 
 // two-phase form of the 8-phase kernel (gemm4p.h), persistent; thin tails are left unsplit (A/B knob LCV_GEMM_TILE=3)
 template <int EPI>
@@ -1184,6 +1188,29 @@ static int launch_gemm4w(GemmParams& p, hipStream_t s) {
   p.vid_begin = 0; p.vid_count = ntiles; p.splitk = 1; p.nk_split = 0; p.ws = nullptr;
   hipLaunchKernelGGL(kern, dim3((unsigned)(ntiles > 256 ? 256 : ntiles)), dim3(NW * 64), lds, s, p);
   LCV_LAUNCH_CHECK("gemm4w_nt");
+  return LCV_OK;
+}
+
+// four waves x 128 x 128 on 64-deep K tiles in 128-byte rows (gemm4k.h, round 4), persistent over all tiles of the launch
+template <int EPI>
+static int launch_gemm4k(GemmParams& p, hipStream_t s) {
+  p.tiles_m = (int)((p.M + 255) / 256);
+  { const char* ge = getenv("LCV_GEMM_GROUP_M"); p.group_m = ge ? atoi(ge) : 6; if (p.group_m < 1) p.group_m = 6; }
+  p.tiles_n = (int)((p.N + 255) / 256);
+  const size_t lds = 2 * 65536;
+  auto kern = gemm4k_nt_kernel<EPI>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      lcv_set_error("gemm_nt: cannot raise dynamic LDS to %zu", lds);
+      return LCV_EDEVICE;
+    }
+    attr_set = true;
+  }
+  const int ntiles = p.tiles_m * p.tiles_n;
+  p.vid_begin = 0; p.vid_count = ntiles; p.splitk = 1; p.nk_split = 0; p.ws = nullptr;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(ntiles > 256 ? 256 : ntiles)), dim3(256), lds, s, p);
+  LCV_LAUNCH_CHECK("gemm4k_nt");
   return LCV_OK;
 }
 
@@ -1245,7 +1272,11 @@ static int dispatch_tile(GemmParams& p, hipStream_t s) {
   const bool ok8t = p.nk1 >= 2 && (uint64_t)256 * p.lda * 2 < (1ull << 31) && (uint64_t)256 * p.ldw * 2 < (1ull << 31) &&
                     (p.nk2 == 0 || ((uint64_t)256 * p.lda2 * 2 < (1ull << 31) && (uint64_t)256 * p.ldw2 * 2 < (1ull << 31)));
   if (mode == 6 && ok8t) mode = 9;  // persistent workgroups (identical to 8 when there are no more tiles than CUs)
-  if (force) mode = force[0] - '0';
+  if (force) mode = force[0] == 'k' ? 10 : force[0] - '0';
+  if constexpr (EPI == LCV_EPI_NONE || EPI == LCV_EPI_GATE_RESIDUAL || EPI == LCV_EPI_SWIGLU) {
+    if (mode == 10 && ok8 && gemm4k_eligible<EPI>(p)) return launch_gemm4k<EPI>(p, s);
+  }
+  if (mode == 10) mode = ok8t ? 9 : 6;
   if (mode == 3 && ok8) return launch_gemm4p<EPI>(p, s);
   if (mode == 4 && ok8) return launch_gemm4w<EPI, 4>(p, s);
   if (mode == 5 && ok8) return launch_gemm4w<EPI, 8>(p, s);

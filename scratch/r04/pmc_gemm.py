@@ -9,7 +9,7 @@ name = sys.argv[1] if len(sys.argv) > 1 else "proj"
 N, K = SH[name]
 M = 93600
 a = torch.randn(M, K, device=dev).to(bf); w = (torch.randn(N, K, device=dev) * 0.02).to(bf); b = torch.randn(N, device=dev).to(bf)
-for tile in ("9", "4"):
+for tile in ("9", "4", "k"):
     os.environ["LCV_GEMM_TILE"] = tile
     for _ in range(6):
         ops.gemm_nt(a, w, b)

@@ -19,6 +19,7 @@ import torch.nn as nn
 
 REF = Path("/root/reference")
 OUT = Path(__file__).resolve().parent
+sys.path.insert(0, str(OUT))
 
 
 def _stub_longcat():
@@ -136,8 +137,18 @@ def main():
         except Exception as e:
             pt.append([c, "ERR:" + type(e).__name__])
     gold["parse_target_blocks"] = pt
-    gold["delta_b_block_to_group"] = {str(G): [min(i // math.ceil(48 / G), G - 1) for i in range(48)] for G in (1, 2, 3, 4, 5, 7, 48)}
-    gold["film_group_idx"] = {str(G): [i * G // 48 for i in range(48)] for G in (1, 2, 3, 4, 5, 7, 48)}
+    # the two group maps are attributes of the reference's wrappers: taken from them (run_delta_b.py:153-157, run_film_tta.py:126-127)
+    from _ref_loader import load_reference_module
+    RB = load_reference_module("delta_experiment/scripts/run_delta_b.py", "ref_run_delta_b")
+    RF = load_reference_module("delta_experiment/scripts/run_film_tta.py", "ref_run_film_tta")
+
+    class _Blocks(nn.Module):
+        def __init__(self, n):
+            super().__init__()
+            self.blocks = nn.ModuleList([nn.Identity() for _ in range(n)])
+    gold["delta_b_block_to_group"] = {str(G): list(RB.DeltaBWrapper(_Blocks(48), num_groups=G).block_to_group) for G in (1, 2, 3, 4, 5, 7, 48)}
+    gold["film_group_idx"] = {str(G): [RF.FiLMAdapterWrapper(_Blocks(48), num_groups=G, hidden_size=8)._get_group_idx(i) for i in range(48)]
+                              for G in (1, 2, 3, 4, 5, 7, 48)}
 
     # ---------------------------------------------------------------- (a11) early-stopper seeds + decision traces
     vids = ["v_ApplyEyeMakeup_g01_c01", "", "panda/000123.mp4", "a" * 40]

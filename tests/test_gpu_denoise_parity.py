@@ -9,7 +9,8 @@ baseline_experiment/scripts/run_baseline.py:409-420) against `oracle/pipeline_or
       bf16-vs-fp32 gap and to north_star's 1e-3 figure;
   K2  49x480p -> [1,16,13,60,104] (20 280 tokens), ALL 48 blocks, one CFG step: whole prediction and Euler update vs the
       oracle, KV-cached == pinned conditioning;
-  K3  49x720p -> [1,16,13,90,160] (46 800 tokens), all 48 blocks, one forward vs the oracle.
+  K3  49x720p -> [1,16,13,90,160] (46 800 tokens), all 48 blocks, one forward vs the oracle;
+  K5  121x480p -> [1,16,31,60,104] (48 360 tokens, BASELINE.json config 5), all 48 blocks, 4 conditioning frames, one forward.
 
 At K2 / K3 the oracle cannot run on host cores in seconds (1.5 PFLOP of fp32 per CFG step), so the SAME oracle code is
 evaluated with plain PyTorch fp32 ops on the card (`device="cuda"`; `test_oracle_is_device_independent` checks that this
@@ -298,6 +299,30 @@ def test_k3_full_depth_forward_vs_oracle(dit48):
     assert torch.isfinite(got).all()
     assert e32 < 1.5 * own + 1e-3                                     # (a)
     assert e < 1.5 * _MEASURED_R2["k3_depth48_forward"]               # (b)
+
+
+def test_k5_full_depth_forward_vs_oracle(dit48):
+    """BASELINE.json config 5 (Panda70M 121-frame clip, 121x480p -> latents [1,16,31,60,104], 48 360 tokens, 48 blocks) on ONE
+    GPU: one forward with 4 conditioning latent frames pinned (the continuation form the long-clip runs use) vs the oracle —
+    the size the sequence-parallel path shards; before round 4 only its shard arithmetic was tested."""
+    from oracle import dit_oracle as D
+    cfg = _full_width_cfg(48)
+    T, ncond = 31, 4
+    hs = torch.randn(1, 16, T, 60, 104, generator=torch.Generator().manual_seed(45)).to(BF16).to(DEV)
+    pe, pm, _, _ = (t.to(DEV) for t in _text())
+    ts = torch.zeros(1, T); ts[:, ncond:] = 800.0
+    ts = ts.to(BF16).to(DEV)
+    with torch.no_grad():
+        got = dit48(hidden_states=hs, timestep=ts, encoder_hidden_states=pe, encoder_attention_mask=pm, num_cond_latents=ncond)
+    P = _P(dit48, DEV)
+    ref = D.dit_forward(P, cfg, hs, ts, pe, pm, ncond, bf16=True)
+    ref32 = D.dit_forward(P, cfg, hs, ts, pe, pm, ncond, bf16=False)
+    e, e32, own = rel_l2(got, ref), rel_l2(got, ref32), rel_l2(ref, ref32)
+    print(f"K5 depth 48 (48 360 tokens, 4 cond frames): prediction HIP-vs-oracle(bf16 points) {e:.2e}, HIP-vs-fp32 {e32:.2e}, "
+          f"oracle bf16-vs-fp32 {own:.2e}")
+    _record("k5_depth48_forward", {"hip_vs_oracle_bf16pts": e, "hip_vs_oracle_fp32": e32, "oracle_bf16pts_vs_fp32": own})
+    assert got.shape == (1, 16, T, 60, 104) and torch.isfinite(got).all()
+    assert e32 < 1.5 * own + 1e-3                                     # (a)
 
 
 def test_text_tokens_zero_pad_branch_matches_oracle():

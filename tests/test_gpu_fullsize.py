@@ -22,6 +22,19 @@ def _ops():
     return ops
 
 
+def _rows(M, n_random, extra=(), g=None):
+    """Row indices for a `x[rows]` spot check: `n_random` random rows of [0, M) plus the hand-picked `extra` ones, range-checked
+    on the HOST before anything is gathered.  ATen's gather does not check: an index past M is an out-of-bounds read on the card
+    (round 3, gpurun_out/r3_all1.log: `2 * line + 7 >= M` fed to `vectorized_gather_kernel` aborted the whole test process)."""
+    extra = [int(e) for e in extra]
+    bad = [e for e in extra if not 0 <= e < M]
+    assert not bad, f"row indices {bad} outside [0, {M})"
+    rnd = torch.randint(0, M, (n_random,), generator=g, device=DEV) if n_random else torch.empty(0, dtype=torch.int64, device=DEV)
+    rows = torch.cat([rnd, torch.tensor(extra, dtype=torch.int64, device=DEV)]) if extra else rnd
+    assert rows.numel() and 0 <= int(rows.min()) and int(rows.max()) < M
+    return rows
+
+
 def test_attention_k3_rows_vs_fp32_and_properties():
     ops = _ops()
     g = torch.Generator(device=DEV).manual_seed(101)
@@ -31,7 +44,7 @@ def test_attention_k3_rows_vs_fp32_and_properties():
     o, lse = ops.attention(q, k, v, scale, need_lse=True)
     assert torch.isfinite(o).all()
     # (i) 48 random query rows x 4 heads against fp32 softmax(QK^T)V over all 46 800 keys
-    rows = torch.randint(0, N_K3, (48,), generator=g, device=DEV)
+    rows = _rows(N_K3, 48, g=g)
     for h in (0, 7, 19, 31):
         s = (q[0, rows, h].float() @ k[0, :, h].float().t()) * scale
         ref = torch.softmax(s, dim=-1) @ v[0, :, h].float()
@@ -65,7 +78,7 @@ def test_gemm_k3_rows_vs_fp32_and_linearity(name, N, K):
     w = (torch.randn((N, K), generator=g, device=DEV) * 0.02).to(BF16)
     b = torch.randn((N,), generator=g, device=DEV).to(BF16)
     c = ops.gemm_nt(a, w, b)
-    rows = torch.cat([torch.randint(0, M, (96,), generator=g, device=DEV), torch.tensor([0, M - 1, M - 208, 255, 256], device=DEV)])
+    rows = _rows(M, 96, (0, M - 1, M - 208, 255, 256), g)
     ref = a[rows].float() @ w.float().t() + b.float()
     assert rel_l2(c[rows], ref) < 2e-3
     a2 = torch.randn((M, K), generator=g, device=DEV).to(BF16)
@@ -88,7 +101,7 @@ def test_swiglu_gemm_k3_rows_vs_fp32():
     wi = torch.stack([w1.view(F_ // 32, 32, C), w3.view(F_ // 32, 32, C)], dim=1).reshape(2 * F_, C).contiguous()
     out = ops.gemm_nt(a, wi, None, epilogue=LCV_EPI_SWIGLU)
     assert out.shape == (N_K3, F_)
-    rows = torch.randint(0, N_K3, (64,), generator=g, device=DEV)
+    rows = _rows(N_K3, 64, g=g)
     gate = (a[rows].float() @ w1.float().t()).to(BF16).float()
     up = (a[rows].float() @ w3.float().t()).to(BF16).float()
     ref = Fn.silu(gate).to(BF16).float() * up
@@ -102,7 +115,7 @@ def test_adaln_and_qknorm_rope_k3_vs_fp32():
     x = torch.randn((2, N_K3, C), generator=g, device=DEV).to(BF16)
     mod = torch.randn((2, T, 6 * C), generator=g, device=DEV) * 0.1
     y = ops.adaln_modulate(x, mod, 3, 4, T)
-    rows = torch.randint(0, N_K3, (64,), generator=g, device=DEV)
+    rows = _rows(N_K3, 64, g=g)
     xf = x[:, rows].float()
     frame = rows // (N_K3 // T)
     xn = torch.nn.functional.layer_norm(xf, (C,), eps=1e-6)
@@ -153,8 +166,8 @@ def test_attention_backward_k3_tta_rows_vs_fp32():
     dqkv = torch.zeros_like(qkv)
     ops.attention_bwd(q, k, v, o, do, lse, dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2], scale)
     assert torch.isfinite(dqkv).all()
-    ks = torch.randint(0, N, (40,), generator=g, device=DEV)
-    rs = torch.randint(0, N, (40,), generator=g, device=DEV)
+    ks = _rows(N, 40, g=g)
+    rs = _rows(N, 40, g=g)
     for h in (0, 13, 31):
         qf, kf, vf, of, dof = (t[0, :, h].float() for t in (q, k, v, o, do))
         delta = (dof * of).sum(-1)                                  # [N]
@@ -227,7 +240,7 @@ def test_dense_weight_and_bias_gradients_full_size_vs_fp32(M, N, K):
     dw = ops.dense_wgrad(dyT, xT)
     db = ops.rowsum(dyT)
     assert dw.shape == (N, K) and dw.dtype == BF16
-    rows = torch.randperm(N, generator=torch.Generator().manual_seed(1))[:48].to(DEV)
+    rows = _rows(N, 0, torch.randperm(N, generator=torch.Generator().manual_seed(1))[:48].tolist())
     ref = dy[:, rows].float().t() @ x.float()                       # [48, K] fp32
     assert rel_l2(dw[rows], ref) < 3e-3, rel_l2(dw[rows], ref)
     ref_b = dy.float().sum(0)
@@ -274,8 +287,7 @@ def test_attention_k3p_176400_tokens_rows_vs_fp32_and_key_permutation():
     q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
     o, lse = ops.attention(q, k, v, ops.LN2, need_lse=True)
     assert torch.isfinite(o).all()
-    rows = torch.cat([torch.randint(0, N_K3P, (40,), generator=g, device=DEV),
-                      torch.tensor([0, 255, 256, N_K3P // 2, N_K3P - 257, N_K3P - 2, N_K3P - 1], device=DEV)])
+    rows = _rows(N_K3P, 40, (0, 255, 256, N_K3P // 2, N_K3P - 257, N_K3P - 2, N_K3P - 1), g)
     for h in (0, 11, 31):
         s = (q[0, rows, h].float() @ k[0, :, h].float().t()) * ops.LN2
         ref = torch.softmax(s, dim=-1) @ v[0, :, h].float()
@@ -300,9 +312,7 @@ def test_gemm_w2_k3p_cfg_batch_rows_past_4gb_vs_fp32(monkeypatch):
     b = torch.randn((N,), generator=g, device=DEV).to(BF16)
     c = ops.gemm_nt(a, w, b)
     line = 2 ** 32 // (2 * K)                                          # first row whose bytes cross 4 GiB
-    rows = torch.cat([torch.randint(0, M, (64,), generator=g, device=DEV),
-                      torch.tensor([0, 255, 256, line - 1, line, line + 1, line + 77777, M - 257, M - 96, M - 1], device=DEV)])
-    assert int(rows.max()) < M and int(rows.min()) >= 0          # (torch's gather does not check: an index past M is a GPU fault)
+    rows = _rows(M, 64, (0, 255, 256, line - 1, line, line + 1, line + 77777, M - 257, M - 96, M - 1), g)
     ref = a[rows].float() @ w.float().t() + b.float()
     assert rel_l2(c[rows], ref) < 2e-3
     worst = ((c[rows].float() - ref).norm(dim=1) / ref.norm(dim=1)).max().item()
