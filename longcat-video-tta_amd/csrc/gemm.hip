@@ -1272,6 +1272,10 @@ static int dispatch_tile(GemmParams& p, hipStream_t s) {
   const bool ok8t = p.nk1 >= 2 && (uint64_t)256 * p.lda * 2 < (1ull << 31) && (uint64_t)256 * p.ldw * 2 < (1ull << 31) &&
                     (p.nk2 == 0 || ((uint64_t)256 * p.lda2 * 2 < (1ull << 31) && (uint64_t)256 * p.ldw2 * 2 < (1ull << 31)));
   if (mode == 6 && ok8t) mode = 9;  // persistent workgroups (identical to 8 when there are no more tiles than CUs)
+  // round 4: the four-wave K64 kernel (gemm4k.h) where its single epilogue serves the call (bf16 output, N a multiple of 256,
+  // 16-byte aligned operands of the epilogue): +4 ... +20 % over the 8-phase kernel at every DiT shape, bit-identical
+  // (profiles/r04_gemm_ab.md); LCV_GEMM_TILE=9 selects the 8-phase kernel again
+  if (mode == 9 && ok8) mode = 10;
   if (force) mode = force[0] == 'k' ? 10 : force[0] - '0';
   if constexpr (EPI == LCV_EPI_NONE || EPI == LCV_EPI_GATE_RESIDUAL || EPI == LCV_EPI_SWIGLU) {
     if (mode == 10 && ok8 && gemm4k_eligible<EPI>(p)) return launch_gemm4k<EPI>(p, s);

@@ -30,7 +30,7 @@
 // tile, 20 us of a 112 us tile at the qkv shape (profiles/r04_gemm_ab.md).  Hence: every load (bias, gate, residual rows) is
 // issued BEFORE the first store of the rows it serves, so its wait counts only younger operations; there is no second code path
 // (what a tile may need is decided on the host, `gemm4k_eligible`): rows past M are predicated off, a wave tile that straddles
-// two latent frames (different gate rows) makes a second pass over its rows with the other frame's gate.
+// two latent frames keeps both frames' gate rows and picks per row.
 // PAIRED accumulator layout: acc[i][j][e] = C[mw + 16 i + r16][nw + 32 (j >> 1) + 8 q + 4 (j & 1) + e]; the same expressions as
 // gemm16_epilogue, operand for operand (bit-identical results), with 16-byte loads and stores.
 template <int EPI>
@@ -73,50 +73,62 @@ __device__ __forceinline__ void g4k_epilogue(const GemmParams& p, f32x4v (&acc)[
       __builtin_amdgcn_sched_barrier(0);
     }
   } else if constexpr (EPI == LCV_EPI_GATE_RESIDUAL) {
-    // gate rows: frame f0 = the tile's first row's; rows at or past `mb` belong to frame f0 + 1 (rows_per_frame >= 128: at most
-    // one boundary inside 128 rows) and are written by a second pass
-    const int64_t f0 = mw / p.rows_per_frame;
+    // gate rows: frame f0 = the tile's first row's; rows at or past `mb` belong to frame f0 + 1 (rows_per_frame >= 128: at most one
+    // boundary inside 128 rows).  BOTH frames' gate values are kept (64 registers) and every lane picks per row block: no second
+    // code path and no loop around the accumulator reads (hipcc hoists AGPR reads out of a loop: 256 live registers).
+    const int64_t f0 = (mw <= m_last_ok ? mw : m_last_ok) / p.rows_per_frame;   // (a wave tile wholly past M must not index past the table)
     const int64_t mb = (f0 + 1) * p.rows_per_frame;
-    const bool straddle = p.gate != nullptr && mb < mw + 128 && mb <= m_last_ok;
     const int64_t off0 = nw + 8 * q;
-    // residual rows 0..3, then (requested before any store) rows 4..7: a row past M reads row M - 1 (never stored)
-    u16x8 res[8][4];
-    auto load_res = [&](int i) {
+    f32x4 ga[4][2], gb[4][2];
+    if (p.gate) {
+      const float* grow = p.gate + f0 * p.mod_stride + off0;
+      const float* grow_b = mb <= m_last_ok ? grow + p.mod_stride : grow;     // (no frame f0 + 1 when the matrix ends first)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        ga[u][0] = *reinterpret_cast<const f32x4*>(grow + 32 * u); ga[u][1] = *reinterpret_cast<const f32x4*>(grow + 32 * u + 4);
+        gb[u][0] = *reinterpret_cast<const f32x4*>(grow_b + 32 * u); gb[u][1] = *reinterpret_cast<const f32x4*>(grow_b + 32 * u + 4);
+      }
+    }
+    // Row block by row block, pinned by compiler fences: the residual row of block i + 1 is requested BEFORE block i is stored, so
+    // the wait for it counts only the four younger stores (no drain) and two residual rows are the most that is live (the first
+    // form of this epilogue let hipcc hoist all 32 residual loads: 512 registers, and the K loop's own DMA sources were spilled -
+    // a scratch reload and a full wait in front of every LDS-DMA piece, 320 TF/s).  A row past M reads row M - 1 (never stored).
+#define G4K_FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+    u16x8 rcur[4], rnxt[4], out[4];
+    auto load_res = [&](int i, u16x8 (&r)[4]) {
       const int64_t m = m_first + 16 * i <= m_last_ok ? m_first + 16 * i : m_last_ok;
       const bf16_t* rrow = p.resid + m * p.ldc + off0;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) res[i][u] = *reinterpret_cast<const u16x8*>(rrow + 32 * u);
+      for (int u = 0; u < 4; ++u) r[u] = *reinterpret_cast<const u16x8*>(rrow + 32 * u);
     };
+    load_res(0, rcur);
+    G4K_FENCE();
 #pragma unroll
-    for (int i = 0; i < 8; ++i) load_res(i);
-    for (int pass = 0; pass < (straddle ? 2 : 1); ++pass) {
-      f32x4 g0[4], g1[4];
-      if (p.gate) {
-        const float* grow = p.gate + (f0 + pass) * p.mod_stride + off0;
+    for (int i = 0; i < 8; ++i) {
+      const int64_t m = m_first + 16 * i;
+      const bool hi = m >= mb;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { g0[u] = *reinterpret_cast<const f32x4*>(grow + 32 * u); g1[u] = *reinterpret_cast<const f32x4*>(grow + 32 * u + 4); }
-      }
-      bf16_t* crow = (bf16_t*)p.c + m_first * p.ldc + off0;
+      for (int u = 0; u < 4; ++u)
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int64_t m = m_first + 16 * i;
-        const bool ok = m <= m_last_ok && (!p.gate || ((m >= mb) == (pass == 1)));
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          u16x8 o;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            float v = acc[i][2 * u + (e >> 2)][e & 3];
-            if (p.bias) v += bf2f(b8[u][e]);
-            const float g = p.gate ? (e < 4 ? g0[u][e & 3] : g1[u][e & 3]) : 1.0f;
-            o[e] = f2bf(bf2f(res[i][u][e]) + g * bfround(v));
-          }
-          if (ok) *reinterpret_cast<u16x8*>(crow + 32 * u) = o;
+        for (int e = 0; e < 8; ++e) {
+          float v = acc[i][2 * u + (e >> 2)][e & 3];
+          if (p.bias) v += bf2f(b8[u][e]);
+          const float g = p.gate ? (hi ? gb[u][e >> 2][e & 3] : ga[u][e >> 2][e & 3]) : 1.0f;
+          out[u][e] = f2bf(bf2f(rcur[u][e]) + g * bfround(v));
         }
-        crow += 16 * p.ldc;
-        __builtin_amdgcn_sched_barrier(0);
+      G4K_FENCE();
+      if (i < 7) load_res(i + 1, rnxt);
+      G4K_FENCE();
+      if (m <= m_last_ok) {
+        bf16_t* crow = (bf16_t*)p.c + m * p.ldc + off0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) *reinterpret_cast<u16x8*>(crow + 32 * u) = out[u];
       }
+      G4K_FENCE();
+#pragma unroll
+      for (int u = 0; u < 4; ++u) rcur[u] = rnxt[u];
     }
+#undef G4K_FENCE
   } else if constexpr (EPI == LCV_EPI_SWIGLU) {
     // W rows interleaved [32 gate | 32 up] per 64 columns: 32-column blocks u = 2 b (gate) and 2 b + 1 (up) of the same 32 features
     bf16_t* crow = (bf16_t*)p.c + m_first * p.ldc + nw / 2 + 8 * q;

@@ -211,7 +211,8 @@ def test_attention_strided_packed_qkv_and_spike():
 
 @pytest.mark.parametrize("M,N,K,tile", [(300, 192, 128, "1"), (70, 64, 64, "1"), (2050, 1024, 256, "2"), (513, 768, 192, "2"), (700, 300, 1088, "2"), (2050, 1024, 256, "6"), (513, 768, 192, "6"), (700, 300, 1088, "6"), (300, 192, 128, "7"), (70, 64, 64, "7"),
                                           (2050, 1024, 256, "8"), (513, 768, 192, "8"), (700, 300, 1088, "8"), (300, 192, 128, "8"),
-                                          (2050, 1024, 256, "9"), (513, 768, 192, "9"), (300, 192, 128, "9")])
+                                          (2050, 1024, 256, "9"), (513, 768, 192, "9"), (300, 192, 128, "9"),
+                                          (2050, 1024, 256, "k"), (513, 768, 192, "k"), (300, 192, 128, "k")])
 def test_gemm_nt_bias(M, N, K, tile, monkeypatch):
     monkeypatch.setenv("LCV_GEMM_TILE", tile)
     ops, orc = _ops(), _orc()
@@ -223,7 +224,7 @@ def test_gemm_nt_bias(M, N, K, tile, monkeypatch):
     assert rel_l2(c32, orc.linear(a, w, b)) < 1e-5
 
 
-@pytest.mark.parametrize("tile", ["1", "7", "8", "9"])
+@pytest.mark.parametrize("tile", ["1", "7", "8", "9", "k"])
 def test_gemm_nt_lora_and_epilogues(tile, monkeypatch):
     monkeypatch.setenv("LCV_GEMM_TILE", tile)
     ops, orc = _ops(), _orc()
@@ -311,10 +312,61 @@ def test_gemm_four_wave_stream_kernel_bitwise(monkeypatch):
             kw = dict(a2=_randn(M, K2, seed=seed + 3).to(DEV), w2=_randn(N, K2, seed=seed + 4, scale=0.05).to(DEV))
         monkeypatch.setenv("LCV_GEMM_TILE", "6")
         ref = ops.gemm_nt(a, w, b, **kw)
-        for tile in ("4", "5"):    # 5 = the same stream design on 8 waves (128 x 64 per wave)
+        for tile in ("4", "5", "k"):    # 5 = the same stream design on 8 waves (128 x 64 per wave); k = gemm4k.h (round 4, the default)
             monkeypatch.setenv("LCV_GEMM_TILE", tile)
             for _ in range(3):
                 assert torch.equal(ops.gemm_nt(a, w, b, **kw), ref), (M, N, K, K2, tile)
+
+
+@pytest.mark.parametrize("M,N,K,K2,kind", [(300, 512, 256, 0, "plain"), (256 * 3 + 19, 512, 512, 0, "plain"), (2500, 512, 192, 128, "plain"),
+                                           (256 * 37 + 19, 256 * 11, 512, 0, "plain"), (4096 + 70, 2048, 4096, 64, "plain"),
+                                           (4096, 1024, 1024, 0, "gate"), (4096 + 33, 1024, 1024, 64, "gate"), (4096 + 33, 1024, 1024, 0, "gate_nomod"),
+                                           (4096, 2048, 1024, 0, "swiglu"), (4096 + 7, 2048, 1024, 0, "swiglu_train"), (12480, 4096, 4096, 0, "gate"),
+                                           (1000, 768, 256, 0, "nobias"), (4680, 1024, 512, 0, "gate_exact_table")])
+def test_gemm4k_default_kernel_bitwise_every_epilogue(M, N, K, K2, kind, monkeypatch):
+    """csrc/gemm4k.h (round 4, the default for the DiT's big GEMMs): four waves x 128 x 128, 64-deep K tiles in 128-byte rows, three
+    barriers per K tile, ONE epilogue with 16-byte stores on a PAIRED column layout (a permutation of the weight rows inside the
+    LDS-DMA).  Same MFMA and K order as the one-barrier kernel (LCV_GEMM_TILE=6): every output bit-identical - rows past M
+    predicated off (ragged M), more tiles than CUs, the rank-r K tiles, the gate row changing INSIDE a wave tile (rows_per_frame not
+    a multiple of 128), no gate, no bias, SwiGLU with and without the pre-activation rows, repeated launches."""
+    ops = _ops()
+    from lcv_hip.lib import LCV_EPI_GATE_RESIDUAL, LCV_EPI_SWIGLU
+    a = _randn(M, K, seed=1).to(DEV); w = _randn(N, K, seed=2, scale=0.05).to(DEV)
+    b = None if kind == "nobias" else _randn(N, seed=3).to(DEV)
+    kw = {}
+    if K2:
+        kw.update(a2=_randn(M, K2, seed=4).to(DEV), w2=_randn(N, K2, seed=5, scale=0.05).to(DEV))
+    if kind == "gate":
+        T = 4
+        kw.update(epilogue=LCV_EPI_GATE_RESIDUAL, resid=_randn(M, N, seed=6).to(DEV), mod=_randn(1, T, 3 * N, seed=7, dtype=torch.float32).to(DEV),
+                  gate_idx=2, rows_per_frame=(M + T - 1) // T)
+    if kind == "gate_nomod":
+        kw.update(epilogue=LCV_EPI_GATE_RESIDUAL, resid=_randn(M, N, seed=6).to(DEV))
+    if kind == "gate_exact_table":
+        # 3 frames of 1 560 rows and a table of exactly 3 gate rows that ENDS its allocation: the last 256-row tile has a wave tile
+        # wholly past M (rows 4 736 ...), whose frame index must not be looked up (round 4: a GPU fault in the first form)
+        mod = _randn(3 * 3 * N, seed=7, dtype=torch.float32).to(DEV).view(1, 3, 3 * N)
+        kw.update(epilogue=LCV_EPI_GATE_RESIDUAL, resid=_randn(M, N, seed=6).to(DEV), mod=mod, gate_idx=2, rows_per_frame=1560)
+    if kind.startswith("swiglu"):
+        kw.update(epilogue=LCV_EPI_SWIGLU)
+    aux_ref = None
+    monkeypatch.setenv("LCV_GEMM_TILE", "6")
+    if kind == "swiglu_train":
+        kw.update(swiglu_aux=torch.empty(M, N, device=DEV, dtype=BF16))
+    ref = ops.gemm_nt(a, w, b, **kw)
+    if kind == "swiglu_train":
+        aux_ref = kw["swiglu_aux"].clone()
+    for tile in ("k", None):          # forced, then the dispatcher's own choice
+        if tile is None:
+            monkeypatch.delenv("LCV_GEMM_TILE")
+        else:
+            monkeypatch.setenv("LCV_GEMM_TILE", tile)
+        for _ in range(2):
+            if aux_ref is not None:
+                kw["swiglu_aux"].zero_()
+            assert torch.equal(ops.gemm_nt(a, w, b, **kw), ref), (M, N, K, K2, kind, tile)
+            if aux_ref is not None:
+                assert torch.equal(kw["swiglu_aux"], aux_ref)
 
 
 @pytest.mark.parametrize("M,N,K,kind", [(12480, 4096, 4096, "plain"), (12480, 4096, 4096, "gate_residual"),
@@ -337,6 +389,7 @@ def test_gemm_splitk_tail_matches_unsplit_and_fp32(M, N, K, kind, monkeypatch):
         kw = dict(a2=_randn(M, 64, seed=86).to(DEV), w2=_randn(N, 64, seed=87, scale=0.05).to(DEV))
     if kind == "f32out":
         kw = dict(out_f32=True)
+    monkeypatch.setenv("LCV_GEMM_TILE", "9")                          # the 8-phase kernel (gemm4k.h, the default since round 4, has no split tail)
     monkeypatch.setenv("LCV_GEMM_SPLITK_TAIL", "0")
     ref = ops.gemm_nt(a, w, b, **kw)
     monkeypatch.delenv("LCV_GEMM_SPLITK_TAIL")
