@@ -516,16 +516,9 @@ static int attn_bwd_qsplit(int64_t B, int64_t H, int64_t Nq, int64_t Nk) {
   return qsplit < 1 ? 1 : qsplit;
 }
 
-// pass A, third form (attn_bwd_dkv3.hip, round 3): 256 keys per workgroup, one wave per SIMD, software-pipelined
-int attn_bwd_dkv3_launch(const void* q, const void* k, const void* v, const void* d_o, const float* consts,
-                         void* dk, void* dv, int accumulate_kv, int64_t B, int64_t H, int64_t Nq, int64_t Nk, int64_t q_sb,
-                         int64_t q_sn, int64_t q_sh, int64_t k_sb, int64_t k_sn, int64_t k_sh, int64_t v_sb, int64_t v_sn,
-                         int64_t v_sh, int64_t o_sb, int64_t o_sn, int64_t o_sh, int64_t dk_sb, int64_t dk_sn, int64_t dk_sh,
-                         int64_t dv_sb, int64_t dv_sn, int64_t dv_sh, float scale, hipStream_t s);
-
 // floats of `delta_ws` a call of lcv_attn_bwd with these sizes needs (host-only; a size, not a status).  An UPPER bound: the
 // per-split dK / dV slices (`qs` x B x H x Nk x 256 floats) are counted whenever the query sweep of these sizes would be split,
-// although a unit-scale call that takes the second / third-form pass A does not touch them (only few-key shapes split: <= 128
+// although a unit-scale call that takes the second-form pass A does not touch them (only few-key shapes split: <= 128
 // keys, so the term is at most 64 x B x H x 128 x 256 floats).
 extern "C" int64_t lcv_attn_bwd_ws_floats(int64_t B, int64_t H, int64_t Nq, int64_t Nk) {
   if (B <= 0 || H <= 0 || Nq < 0 || Nk <= 0) return 0;
@@ -572,17 +565,9 @@ extern "C" int lcv_attn_bwd(const void* q, const void* k, const void* v, const v
   const char* bve = getenv("LCV_ATTN_BWD_VAR");  // A/B knob: bit 0 = second-form pass B (dQ), bit 1 = second-form pass A (dK, dV)
   const int bvar = bve ? (bve[0] - '0') & 3 : 3;
   const bool unit = p.scale_log2e > 1.0f - 4e-7f && p.scale_log2e < 1.0f + 4e-7f;
-  // A/B knob LCV_ATTN_BWD_DKV=3: the third form of pass A (attn_bwd_dkv3.hip: one wave per SIMD, software-pipelined, bit-identical).
-  // NOT the default: 15.8 vs 13.4 ms per layer at the K3-TTA shape - with one wave per SIMD nothing covers an LDS round trip, the
-  // stamps (scratch/attn_lab/dkv3_main.cpp) show 47 / 72 cycles per MFMA in its two phases against 32 (profiles/r03_attn_bwd_lab.md)
-  const char* dkve = getenv("LCV_ATTN_BWD_DKV");
-  const bool dkv3 = dkve && dkve[0] == '3';
-  if (unit && (bvar & 2) && dkv3) {
-    const int rc = attn_bwd_dkv3_launch(q, k, v, d_o, delta_ws + B * H * Nq /* the padded -lse2 / -delta rows */, dk, dv, accumulate_kv, B, H, Nq, Nk,
-                                        q_sb, q_sn, q_sh, k_sb, k_sn, k_sh, v_sb, v_sn, v_sh, o_sb, o_sn, o_sh, dk_sb, dk_sn, dk_sh, dv_sb, dv_sn,
-                                        dv_sh, scale, s);
-    if (rc != LCV_OK) return rc;
-  } else if (unit && (bvar & 2)) {
+  // (a third form of pass A - one wave per SIMD, software-pipelined, bit-identical, 2 % slower - was built in round 3 and is kept
+  // under scratch/tried/attn_bwd_dkv3_r3_one_wave_per_simd.hip.txt with its numbers in profiles/r03_attn_bwd_lab.md)
+  if (unit && (bvar & 2)) {
     const int rc = attn_bwd_dkv2_launch(q, k, v, d_o, lse, delta_ws + B * H * Nq /* the padded -lse2 / -delta rows */, dk, dv, accumulate_kv, B, H, Nq, Nk, q_sb, q_sn, q_sh, k_sb, k_sn,
                                         k_sh, v_sb, v_sn, v_sh, o_sb, o_sn, o_sh, dk_sb, dk_sn, dk_sh, dv_sb, dv_sn, dv_sh, scale, s);
     if (rc != LCV_OK) return rc;

@@ -17,7 +17,7 @@
 //                                                                   K(t+3) / V(t+2), first fragments of K(t+2)
 //                  post      rare: rescale O, l and S(t+1) of a block whose running max grew by more than 2^RESCALE_THR
 // MFMAs are issued from asm with the register class pinned (score sets in arch VGPRs, O in AGPRs, Q fragments as AGPR B
-// operands): left alone hipcc puts every MFMA result of a > 256-register kernel into AGPRs (attn_bwd_dkv3.hip).  asm is opaque
+// operands): left alone hipcc puts every MFMA result of a > 256-register kernel into AGPRs (round 3, scratch/tried/attn_bwd_dkv3_r3_one_wave_per_simd.hip.txt).  asm is opaque
 // to the hazard recogniser: see GUARD below and profiles/r03_attn_bwd_lab.md for the four ways that went wrong before.
 #include "lcv_common.h"
 #include <type_traits>

@@ -1141,61 +1141,15 @@ static int launch_conv8p(GemmParams& p, hipStream_t s) {
   return LCV_OK;
 }
 
-#include "gemm4w.h"
-#include "gemm4p.h"
 #include "gemm4k.h"
-
-// two-phase form of the 8-phase kernel (gemm4p.h), persistent; thin tails are left unsplit (A/B knob LCV_GEMM_TILE=3)
-template <int EPI>
-static int launch_gemm4p(GemmParams& p, hipStream_t s) {
-  p.tiles_m = (int)((p.M + 255) / 256);
-  { const char* ge = getenv("LCV_GEMM_GROUP_M"); p.group_m = ge ? atoi(ge) : 6; if (p.group_m < 1) p.group_m = 6; }
-  p.tiles_n = (int)((p.N + 255) / 256);
-  const size_t lds = 2 * 65536;
-  auto kern = gemm4p_nt_kernel<EPI, true>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-      lcv_set_error("gemm_nt: cannot raise dynamic LDS to %zu", lds);
-      return LCV_EDEVICE;
-    }
-    attr_set = true;
-  }
-  const int ntiles = p.tiles_m * p.tiles_n;
-  p.vid_begin = 0; p.vid_count = ntiles; p.splitk = 1; p.nk_split = 0; p.ws = nullptr;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(ntiles > 256 ? 256 : ntiles)), dim3(512), lds, s, p);
-  LCV_LAUNCH_CHECK("gemm4p_nt");
-  return LCV_OK;
-}
-
-// four waves x 128 x 128 (gemm4w.h), persistent over all tiles of the launch
-template <int EPI, int NW>
-static int launch_gemm4w(GemmParams& p, hipStream_t s) {
-  p.tiles_m = (int)((p.M + 255) / 256);
-  { const char* ge = getenv("LCV_GEMM_GROUP_M"); p.group_m = ge ? atoi(ge) : 6; if (p.group_m < 1) p.group_m = 6; }
-  p.tiles_n = (int)((p.N + 255) / 256);
-  const size_t lds = 2 * 65536;
-  auto kern = gemm4w_nt_kernel<EPI, NW>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-      lcv_set_error("gemm_nt: cannot raise dynamic LDS to %zu", lds);
-      return LCV_EDEVICE;
-    }
-    attr_set = true;
-  }
-  const int ntiles = p.tiles_m * p.tiles_n;
-  p.vid_begin = 0; p.vid_count = ntiles; p.splitk = 1; p.nk_split = 0; p.ws = nullptr;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(ntiles > 256 ? 256 : ntiles)), dim3(NW * 64), lds, s, p);
-  LCV_LAUNCH_CHECK("gemm4w_nt");
-  return LCV_OK;
-}
 
 // four waves x 128 x 128 on 64-deep K tiles in 128-byte rows (gemm4k.h, round 4), persistent over all tiles of the launch
 template <int EPI>
 static int launch_gemm4k(GemmParams& p, hipStream_t s) {
   p.tiles_m = (int)((p.M + 255) / 256);
-  { const char* ge = getenv("LCV_GEMM_GROUP_M"); p.group_m = ge ? atoi(ge) : 6; if (p.group_m < 1) p.group_m = 6; }
+  // tile rows per group of the XCD-contiguous tile order: 3 measured best for this kernel (1 ... 64 swept in one process at the
+  // qkv / w13 / proj shapes, profiles/r04_gemm_ab.md: 1435 / 1358 / 1411 TF/s at 3, 1398 / 1353 / 1420 at 6, 1254 / 1251 / 1275 at 16)
+  { const char* ge = getenv("LCV_GEMM_GROUP_M"); p.group_m = ge ? atoi(ge) : 3; if (p.group_m < 1) p.group_m = 3; }
   p.tiles_n = (int)((p.N + 255) / 256);
   const size_t lds = 2 * 65536;
   auto kern = gemm4k_nt_kernel<EPI>;
@@ -1281,9 +1235,6 @@ static int dispatch_tile(GemmParams& p, hipStream_t s) {
     if (mode == 10 && ok8 && gemm4k_eligible<EPI>(p)) return launch_gemm4k<EPI>(p, s);
   }
   if (mode == 10) mode = ok8t ? 9 : 6;
-  if (mode == 3 && ok8) return launch_gemm4p<EPI>(p, s);
-  if (mode == 4 && ok8) return launch_gemm4w<EPI, 4>(p, s);
-  if (mode == 5 && ok8) return launch_gemm4w<EPI, 8>(p, s);
   if (mode == 8 && ok8t) return launch_gemm8p<EPI, false>(p, s);
   if (mode == 9 && ok8t) return launch_gemm8p<EPI, true>(p, s);
   if (mode == 6 || mode == 8 || mode == 9) return launch_gemm16<256, 256, 2, 4, EPI, false>(p, s);

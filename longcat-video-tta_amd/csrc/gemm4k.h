@@ -1,7 +1,7 @@
 // 256 x 256 output tile on FOUR waves (one per SIMD, 128 x 128 each), 64-deep K tiles in 128-byte LDS rows, persistent workgroups
 // that treat the K tiles of all their output tiles as ONE stream.  Included by gemm.hip (GemmParams, gemm_tile_coords,
 // gemm16_epilogue); `LCV_GEMM_TILE=k`.  Round 4: what the counters of profiles/r04_gemm_ab.md say the round-2 four-wave kernel
-// (gemm4w.h) still paid for, against the vendor kernel of the same tile (hipBLASLt `..._MT256x256x64_MI16x16x1`, 0.80 matrix-pipe
+// (`gemm4w.h`, now scratch/tried/) still paid for, against the vendor kernel of the same tile (hipBLASLt `..._MT256x256x64_MI16x16x1`, 0.80 matrix-pipe
 // busy at 1.49 GHz vs 0.61 at 1.88):
 //   * gemm4w stages 32-deep half K tiles in 64-byte rows (a fragment is then one contiguous KiB): every 128-byte line of A and W
 //     is requested TWICE from L2, as two half lines at different times - TCP_TCC_READ_REQ 3.87e8 per launch against 1.92e8 for the
@@ -16,12 +16,35 @@
 //   * the epilogue stores 16 bytes per lane and instruction: the weight rows of every 32-column block are dealt to its two
 //     16-row MFMA tiles so that a lane's values of tiles (2u, 2u + 1) are 8 consecutive columns (a permutation of the DMA's source
 //     rows, free) - 32 store instructions per lane and tile instead of 64, each covering 64-byte row segments instead of 32.
-// Everything else is gemm4w's: accumulators pinned to the AGPR half of the register file by "+a" asm MFMAs (one definition per
+// Kept from gemm4w: accumulators pinned to the AGPR half of the register file by "+a" asm MFMAs (one definition per
 // tile, no branch between a tile's first and last MFMA), every fragment read from LDS once per 64 MFMAs, the stream runs on into
 // the next output tile (its first K tiles are in LDS and its first fragments in registers behind the epilogue), surplus stages
 // past the end of the stream re-fetch the last K tile.  Same MFMA, same K order as every other 16x16x32 kernel here: bit-identical
 // results (tests/test_gpu_kernels.py uses that as the race screen).
 #pragma once
+
+typedef __attribute__((address_space(3))) unsigned char g4_lds_u8;
+
+template <int B, int E, class F>
+__device__ __forceinline__ void g4_static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    g4_static_for<B + 1, E>(f);
+  }
+}
+// everything the K loop issues comes from asm volatile statements: the order in the source is the issue order
+__device__ __forceinline__ void g4_mfma(f32x4v& acc, const bf16x8& w, const bf16x8& a) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(w), "v"(a));
+}
+template <int IMM>
+__device__ __forceinline__ void g4_read(bf16x8& f, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f) : "v"(addr), "n"(IMM));
+}
+__device__ __forceinline__ void g4_set_m0(unsigned dst) { asm volatile("s_mov_b32 m0, %0" ::"s"(dst)); }
+// (no immediate offset: the hardware adds it to the LDS address as well as to the global one)
+__device__ __forceinline__ void g4_dma(unsigned off, const char* base) {
+  asm volatile("global_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base) : "memory");
+}
 
 // ---- the ONE epilogue of this kernel.  With one wave per SIMD nothing runs beside it, and on this ISA loads, stores and LDS-DMA
 // share ONE in-order counter (vmcnt): a wait for ANY load that was issued after a store also waits for that store to be
@@ -313,8 +336,8 @@ __global__ __launch_bounds__(256) void gemm4k_nt_kernel(const GemmParams p) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
     asm volatile("s_nop 7" ::: "memory");
-    // (see gemm4w.h: a wait hipcc can SEE, once per tile, for the previous epilogue's stores - otherwise it parks a vmcnt(0) in
-    // front of the first fragment read inside the K loop, where it would also wait for the LDS-DMA it cannot see)
+    // a wait hipcc can SEE, once per tile, for the previous epilogue's stores - otherwise it parks a vmcnt(0) in front of the first
+    // fragment read inside the K loop, where it would also wait for the LDS-DMA it cannot see
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
     for (int kt = 0; kt < nk; ++kt) {
       k_tile(lds_wave + (dq & 1u) * BUF, st_a + stage_k_bytes(), st_w + stage_k_bytes());
@@ -331,7 +354,7 @@ __global__ __launch_bounds__(256) void gemm4k_nt_kernel(const GemmParams p) {
     vid += stride;
     if (vid >= vid_end) break;
     // the next tile's first fragments were read by the last phase B; reading them AGAIN here makes those registers dead across the
-    // epilogue (gemm4w.h: otherwise hipcc keeps them live through it and spills the epilogue's own values)
+    // epilogue (otherwise hipcc keeps them live through it and spills the epilogue's own values)
     a_rd0 ^= BUF;
     w_rd0 ^= BUF;
     g4_static_for<0, 16>([&](auto t_c) { read_frag(std::integral_constant<int, 0>{}, t_c); });

@@ -28,7 +28,7 @@ def _newest_header():
 # chains may drop IEEE sNaN quieting (bare v_max3_f32 instead of a canonicalising v_max per MFMA output)
 _ATTN_FLAGS = ["-fno-honor-nans", "-mno-amdgpu-ieee", "-fno-slp-vectorize"]
 EXTRA = {"attn_fwd.hip": _ATTN_FLAGS, "attn_fwd_pipe.hip": _ATTN_FLAGS, "attn_bwd_dq2.hip": _ATTN_FLAGS, "attn_bwd_dkv2.hip": _ATTN_FLAGS,
-         "attn_bwd_dkv3.hip": _ATTN_FLAGS, "attn_fwd_w64.hip": _ATTN_FLAGS}
+         "attn_fwd_w64.hip": _ATTN_FLAGS}
 
 
 def _compile(src: Path, hdr_mtime: float) -> Path:

@@ -298,26 +298,6 @@ def test_gemm_persistent_many_tiles_bitwise(monkeypatch):
         assert torch.equal(ops.gemm_nt(a, w, b), ref)
 
 
-def test_gemm_four_wave_stream_kernel_bitwise(monkeypatch):
-    """csrc/gemm4w.h (opt-in, LCV_GEMM_TILE=4): four waves x 128 x 128, accumulators pinned to AGPRs, four 32-deep stage slots,
-    LDS-DMA three stages ahead across output-tile boundaries, one barrier per 64 MFMAs.  Same MFMA, same K order as the
-    one-barrier kernel, so every output must be bit-identical: ragged M / N, more tiles than CUs (the stream crosses tile
-    boundaries), an odd number of K tiles with the rank-r pair (the stage parity flips from tile to tile), repeated launches."""
-    ops = _ops()
-    for (M, N, K, K2, seed) in ((256 * 37 + 19, 256 * 11 + 40, 512, 0, 81), (4096 + 70, 2048 + 30, 4096, 64, 85), (300, 512, 256, 0, 89),
-                                (2500, 512, 192, 128, 93)):
-        a = _randn(M, K, seed=seed).to(DEV); w = _randn(N, K, seed=seed + 1, scale=0.05).to(DEV); b = _randn(N, seed=seed + 2).to(DEV)
-        kw = {}
-        if K2:
-            kw = dict(a2=_randn(M, K2, seed=seed + 3).to(DEV), w2=_randn(N, K2, seed=seed + 4, scale=0.05).to(DEV))
-        monkeypatch.setenv("LCV_GEMM_TILE", "6")
-        ref = ops.gemm_nt(a, w, b, **kw)
-        for tile in ("4", "5", "k"):    # 5 = the same stream design on 8 waves (128 x 64 per wave); k = gemm4k.h (round 4, the default)
-            monkeypatch.setenv("LCV_GEMM_TILE", tile)
-            for _ in range(3):
-                assert torch.equal(ops.gemm_nt(a, w, b, **kw), ref), (M, N, K, K2, tile)
-
-
 @pytest.mark.parametrize("M,N,K,K2,kind", [(300, 512, 256, 0, "plain"), (256 * 3 + 19, 512, 512, 0, "plain"), (2500, 512, 192, 128, "plain"),
                                            (256 * 37 + 19, 256 * 11, 512, 0, "plain"), (4096 + 70, 2048, 4096, 64, "plain"),
                                            (4096, 1024, 1024, 0, "gate"), (4096 + 33, 1024, 1024, 64, "gate"), (4096 + 33, 1024, 1024, 0, "gate_nomod"),

@@ -2,7 +2,7 @@
 """Mechanical screen for the hand-issued MFMAs of this library (hipcc `-S` text in, findings out).
 
 Several kernels issue their MFMAs from `asm volatile` so that the accumulator register class and the program order are what the
-source says (csrc/attn_fwd_w64.hip, attn_bwd_dkv3.hip, attn_fwd_pipe.hip, gemm4w.h).  hipcc's hazard recogniser does not look
+source says (csrc/attn_fwd_w64.hip, attn_fwd_pipe.hip, gemm4k.h).  hipcc's hazard recogniser does not look
 inside an asm statement: when the register allocator puts a copy of an MFMA operand (`v_mov_b32`, `v_accvgpr_write_b32`,
 `v_accvgpr_mov_b32`, any VALU result) right in front of such a statement, nothing inserts the wait states the matrix pipe needs
 between a vector write and an MFMA read of the same register, and the MFMA reads the OLD value — four distinct wrong-result bugs
