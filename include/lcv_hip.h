@@ -40,6 +40,28 @@ const char* lcv_last_error(void);      /* message of the last failure on this th
 /* 0 when the current device is gfx950; LCV_EDEVICE otherwise. */
 int lcv_device_check(void);
 
+/* ---- A/B knobs -------------------------------------------------------
+ * Environment variables the launchers consult to pick between SHIPPED alternatives of a kernel (same results, bit for bit unless
+ * a line says otherwise; defaults are the measured-fastest forms).  They are read ONCE, at the library's first use;
+ * lcv_knobs_reload() reads the environment again (tests and A/B harnesses that flip a knob inside one process; returns the
+ * number of knobs that are set, never an error); lcv_knobs_list() returns the names below, space separated.  Nothing else in the
+ * environment is looked at.
+ *   LCV_GEMM_TILE          k = gemm4k.h (default where its one epilogue serves the call), 9 / 8 = the 8-phase kernel persistent /
+ *                          per-tile, 6 / 7 = one-barrier 256 / 128 tiles (the bit-level reference of the tests), 2 / 1 = the same
+ *                          tiles on the 32x32x16 MFMA
+ *   LCV_GEMM_GROUP_M       tile rows per group of the XCD-contiguous tile order (default 3 for gemm4k, 6 for the 8-phase kernel)
+ *   LCV_GEMM_FAST_EPI      0 = the 8-phase kernel takes the generic epilogue on interior tiles too
+ *   LCV_GEMM_SPLITK_TAIL   0 = the 8-phase kernel does not split a thin last round of tiles along K (summation order differs)
+ *   LCV_CONV_8P, LCV_CONV_N192, LCV_CONV_ROWS, LCV_CONV_ROWS_GRID, LCV_CONV_ROWS_ORDER
+ *                          which convolution kernel / tile order the VAE stages take (csrc/conv_rows.h, conv_wide.h)
+ *   LCV_ATTN_FWD_W64       0 = the two-waves-per-SIMD forward of round 2 instead of attn_fwd_w64_kernel (cross-check; 1.4e-5 apart)
+ *   LCV_ATTN_XCD           0 = no head-per-XCD workgroup order in the forward
+ *   LCV_ATTN_BWD_VAR       bit 0 / bit 1 = second-form pass B / pass A of the backward (default 3; 0 = the general-scale forms)
+ *   LCV_ATTN_BWD_DKV_WAVES, LCV_ATTN_BWD_DQ_WAVES   8 = one 8-wave workgroup per CU instead of two 4-wave ones
+ *   LCV_ATTN_BWD_PIPE, LCV_ATTN_BWD_STAGGER, LCV_ATTN_BWD_XCD   schedule variants of the backward passes measured and left off */
+int lcv_knobs_reload(void);
+const char* lcv_knobs_list(void);
+
 /* ---- AdaLN modulate / LayerNorm ------------------------------------- */
 /* y = LN_noaffine_fp32(x) * (1 + scale[b,t,:]) + shift[b,t,:]  -> bf16
  * x,y: [B, T*S, C] bf16 (S tokens per latent frame); shift/scale: fp32 rows of

@@ -562,7 +562,7 @@ extern "C" int lcv_attn_bwd(const void* q, const void* k, const void* v, const v
                        (const bf16_t*)o, (const bf16_t*)d_o, lse, delta_ws, Nq, (int)H, o_sb, o_sn, o_sh, o_sb, o_sn, o_sh);
     LCV_LAUNCH_CHECK("attn_bwd_delta");
   }
-  const char* bve = getenv("LCV_ATTN_BWD_VAR");  // A/B knob: bit 0 = second-form pass B (dQ), bit 1 = second-form pass A (dK, dV)
+  const char* bve = lcv_knob("LCV_ATTN_BWD_VAR");  // A/B knob: bit 0 = second-form pass B (dQ), bit 1 = second-form pass A (dK, dV)
   const int bvar = bve ? (bve[0] - '0') & 3 : 3;
   const bool unit = p.scale_log2e > 1.0f - 4e-7f && p.scale_log2e < 1.0f + 4e-7f;
   // (a third form of pass A - one wave per SIMD, software-pipelined, bit-identical, 2 % slower - was built in round 3 and is kept
@@ -594,13 +594,11 @@ extern "C" int lcv_attn_bwd(const void* q, const void* k, const void* v, const v
     constexpr int NW = 8;
     const size_t lds = 2 * 2 * 64 * 256;
     auto kern = attn_bwd_dq_kernel<NW>;
-    static bool attr_set = false;
-    if (!attr_set) {
-      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    // (function-local static: initialised once, thread-safe)
+    static const bool attr_ok = !(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess);
+    if (!attr_ok) {
         lcv_set_error("attn_bwd: cannot raise dynamic LDS");
         return LCV_EDEVICE;
-      }
-      attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)((Nq + NW * 32 - 1) / (NW * 32)), (unsigned)H, (unsigned)B),
                        dim3(NW * 64), lds, s, p);

@@ -316,27 +316,25 @@ int attn_bwd_dkv2_launch(const void* q, const void* k, const void* v, const void
   p.v_sb = v_sb; p.v_sn = v_sn; p.v_sh = v_sh; p.o_sb = o_sb; p.o_sn = o_sn; p.o_sh = o_sh;
   p.dk_sb = dk_sb; p.dk_sn = dk_sn; p.dk_sh = dk_sh; p.dv_sb = dv_sb; p.dv_sn = dv_sn; p.dv_sh = dv_sh;
   p.scale = scale; p.accumulate_kv = accumulate_kv;
-  const char* we = getenv("LCV_ATTN_BWD_DKV_WAVES");   // A/B knob: 4 = two 4-wave workgroups per CU (128 keys each), 8 = one 8-wave (256 keys)
+  const char* we = lcv_knob("LCV_ATTN_BWD_DKV_WAVES");   // A/B knob: 4 = two 4-wave workgroups per CU (128 keys each), 8 = one 8-wave (256 keys)
   const int nw = (we && we[0] == '8') ? 8 : 4;
   const size_t lds = (size_t)nw * 32 * 256 + 2 * (2 * 32 * 256 + 2 * 32 * 4);
-  static bool attr_set = false;
-  if (!attr_set) {
     const int l4 = 4 * 32 * 256 + 2 * (2 * 32 * 256 + 2 * 32 * 4), l8 = 8 * 32 * 256 + 2 * (2 * 32 * 256 + 2 * 32 * 4);
-    if (hipFuncSetAttribute((const void*)attn_bwd_dkv2_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, l4) != hipSuccess ||
+  // (function-local static: initialised once, thread-safe)
+  static const bool attr_ok = !(hipFuncSetAttribute((const void*)attn_bwd_dkv2_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, l4) != hipSuccess ||
         hipFuncSetAttribute((const void*)attn_bwd_dkv2_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, l4) != hipSuccess ||
-        hipFuncSetAttribute((const void*)attn_bwd_dkv2_kernel<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, l8) != hipSuccess) {
+        hipFuncSetAttribute((const void*)attn_bwd_dkv2_kernel<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, l8) != hipSuccess);
+  if (!attr_ok) {
       lcv_set_error("attn_bwd: cannot raise dynamic LDS");
       return LCV_EDEVICE;
-    }
-    attr_set = true;
   }
-  { const char* se = getenv("LCV_ATTN_BWD_STAGGER"); p.stagger = se ? atoi(se) : 0; if (p.stagger < 0 || p.stagger > 127) p.stagger = 0; }
-  const char* pe = getenv("LCV_ATTN_BWD_PIPE");   // A/B knob: 0 = hipcc's own read / MFMA order
+  { const char* se = lcv_knob("LCV_ATTN_BWD_STAGGER"); p.stagger = se ? atoi(se) : 0; if (p.stagger < 0 || p.stagger > 127) p.stagger = 0; }
+  const char* pe = lcv_knob("LCV_ATTN_BWD_PIPE");   // A/B knob: 0 = hipcc's own read / MFMA order
   const bool pipe = !(pe && pe[0] == '0');
   const unsigned gx = (unsigned)((Nk + nw * 32 - 1) / (nw * 32));
   // A/B knob LCV_ATTN_BWD_XCD=1 enables the head-per-XCD block order.  OFF by default: at the K3-TTA shapes (25 200 keys x 32
   // heads) it measured 27.06 vs 26.51 ms per layer in one process - unlike the forward, these passes are not helped by it
-  const char* xe = getenv("LCV_ATTN_BWD_XCD");
+  const char* xe = lcv_knob("LCV_ATTN_BWD_XCD");
   p.gx = (int)gx;
   p.xcd_remap = ((B * H) % 8 == 0 && gx >= 8 && xe && xe[0] == '1') ? 1 : 0;
   const dim3 grid = p.xcd_remap ? dim3(gx * (unsigned)(H * B)) : dim3(gx, (unsigned)H, (unsigned)B);

@@ -256,22 +256,20 @@ int attn_bwd_dq2_launch(const void* q, const void* k, const void* v, const void*
   p.q_sb = q_sb; p.q_sn = q_sn; p.q_sh = q_sh; p.k_sb = k_sb; p.k_sn = k_sn; p.k_sh = k_sh;
   p.v_sb = v_sb; p.v_sn = v_sn; p.v_sh = v_sh; p.o_sb = o_sb; p.o_sn = o_sn; p.o_sh = o_sh;
   p.dq_sb = dq_sb; p.dq_sn = dq_sn; p.dq_sh = dq_sh; p.scale = scale;
-  const char* we = getenv("LCV_ATTN_BWD_DQ_WAVES");   // A/B knob: 8 = one 8-wave workgroup per CU (4 stages), 4 = two 4-wave ones
+  const char* we = lcv_knob("LCV_ATTN_BWD_DQ_WAVES");   // A/B knob: 8 = one 8-wave workgroup per CU (4 stages), 4 = two 4-wave ones
   const int nw = (we && we[0] == '8') ? 8 : 4;
   const size_t lds = (nw == 8 ? 4 : 2) * 2 * 64 * 256;   // NS stages of (K tile | V tile)
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)attn_bwd_dq2_kernel<8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * 64 * 256) != hipSuccess ||
-        hipFuncSetAttribute((const void*)attn_bwd_dq2_kernel<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 64 * 256) != hipSuccess) {
+  // (function-local static: initialised once, thread-safe)
+  static const bool attr_ok = !(hipFuncSetAttribute((const void*)attn_bwd_dq2_kernel<8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * 64 * 256) != hipSuccess ||
+        hipFuncSetAttribute((const void*)attn_bwd_dq2_kernel<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 64 * 256) != hipSuccess);
+  if (!attr_ok) {
       lcv_set_error("attn_bwd: cannot raise dynamic LDS");
       return LCV_EDEVICE;
-    }
-    attr_set = true;
   }
   const unsigned gx = (unsigned)((Nq + nw * 32 - 1) / (nw * 32));
   // A/B knob LCV_ATTN_BWD_XCD=1 enables the head-per-XCD block order.  OFF by default: at the K3-TTA shapes (25 200 keys x 32
   // heads) it measured 27.06 vs 26.51 ms per layer in one process - unlike the forward, these passes are not helped by it
-  const char* xe = getenv("LCV_ATTN_BWD_XCD");
+  const char* xe = lcv_knob("LCV_ATTN_BWD_XCD");
   p.gx = (int)gx;
   p.xcd_remap = ((B * H) % 8 == 0 && gx >= 8 && xe && xe[0] == '1') ? 1 : 0;
   const dim3 grid = p.xcd_remap ? dim3(gx * (unsigned)(H * B)) : dim3(gx, (unsigned)H, (unsigned)B);

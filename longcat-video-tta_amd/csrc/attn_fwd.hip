@@ -438,10 +438,8 @@ extern "C" int lcv_attn_fwd(const void* q, const void* k, const void* v, void* o
   p.scale = scale; p.scale_log2e = scale * 1.4426950408889634f;
   constexpr int NW = 8;
   const size_t lds = 2 * 2 * 64 * 256;
-  const char* pe = getenv("LCV_ATTN_PRIO");  // 0 none, 1 static priority for waves 4-7 (A/B knob)
-  const int prio = pe ? pe[0] - '0' : 0;
   const unsigned gx = (unsigned)((Nq + NW * 32 - 1) / (NW * 32));
-  const char* xe = getenv("LCV_ATTN_XCD");  // A/B knob: 0 disables the head-per-XCD block order
+  const char* xe = lcv_knob("LCV_ATTN_XCD");  // A/B knob: 0 disables the head-per-XCD block order
   p.gx = (int)gx;
   p.xcd_remap = ((B * H) % 8 == 0 && gx >= 8 && !(xe && xe[0] == '0')) ? 1 : 0;
   const dim3 grid = p.xcd_remap ? dim3(gx * (unsigned)(H * B)) : dim3(gx, (unsigned)H, (unsigned)B);
@@ -453,31 +451,26 @@ extern "C" int lcv_attn_fwd(const void* q, const void* k, const void* v, void* o
     hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, (hipStream_t)stream, p);
     return LCV_OK;
   };
-  const char* ve = getenv("LCV_ATTN_VAR");  // A/B knob: 0 = register-staged K/V tiles instead of LDS-DMA
-  const int var = ve ? (ve[0] - '0') & 1 : 1;
   // Q pre-scaled into log2 units (scale = ln 2): the multiply-free softmax body
   const bool unit = p.scale_log2e > 1.0f - 4e-7f && p.scale_log2e < 1.0f + 4e-7f;
   int rc;
-  const char* pe2 = getenv("LCV_ATTN_PIPE");  // A/B knob: 0 = the phase-ordered kernel of this file instead of attn_fwd_pipe.hip
   // (its LDS-DMA addresses are a scalar base + 32-bit per-lane byte offsets: one (batch, head)'s rows must span < 4 GiB)
   const bool span32 = (uint64_t)Nk * (uint64_t)(k_sn > v_sn ? k_sn : v_sn) * 2 < (1ull << 32) &&
                       (uint64_t)Nq * (uint64_t)q_sn * 2 < (1ull << 32);
   // default since round 3: 64 query rows per wave on one wave per SIMD (attn_fwd_w64.hip; equal to +4 % against the pipelined
   // two-waves-per-SIMD kernel depending on the box, profiles/r03_attn_fwd_lab.md).  A/B knob: LCV_ATTN_FWD_W64=0 = attn_fwd_pipe.hip
-  const char* we = getenv("LCV_ATTN_FWD_W64");
-  if (unit && Nk > 512 && span32 && !(we && we[0] == '0') && !(pe2 && pe2[0] == '0') && prio == 0 && var == 1) {
+  const char* we = lcv_knob("LCV_ATTN_FWD_W64");
+  if (unit && Nk > 512 && span32 && !(we && we[0] == '0')) {
     g_last_attn_kernel = "attn_fwd_w64_kernel";
     return attn_fwd_w64_launch(q, k, v, o, lse, B, H, Nq, Nk, q_sb, q_sn, q_sh, k_sb, k_sn, k_sh, v_sb, v_sn, v_sh, o_sb, o_sn,
                                o_sh, scale, !(xe && xe[0] == '0'), (hipStream_t)stream);
   }
-  if (unit && Nk > 512 && span32 && !(pe2 && pe2[0] == '0') && prio == 0 && var == 1) {
+  if (unit && Nk > 512 && span32) {   // LCV_ATTN_FWD_W64=0: the two-waves-per-SIMD kernel of round 2, kept as the bit-level cross-check of the default
     g_last_attn_kernel = "attn_fwd_pipe_kernel";
     return attn_fwd_pipe_launch(q, k, v, o, lse, B, H, Nq, Nk, q_sb, q_sn, q_sh, k_sb, k_sn, k_sh, v_sb, v_sn, v_sh, o_sb, o_sn,
                                 o_sh, scale, !(xe && xe[0] == '0'), (hipStream_t)stream);
   }
   if (Nk <= 512) { g_last_attn_kernel = "attn_fwd_kernel<8, 0, true, 0>"; rc = launch(attn_fwd_kernel<NW, 0, true, 0>); }
-  else if (prio == 1) { g_last_attn_kernel = "attn_fwd_kernel<8, 1, false, 0>"; rc = launch(attn_fwd_kernel<NW, 1, false, 0>); }
-  else if (var == 0) { g_last_attn_kernel = "attn_fwd_kernel<8, 0, false, 0>"; rc = launch(attn_fwd_kernel<NW, 0, false, 0>); }
   else if (unit) { g_last_attn_kernel = "attn_fwd_kernel<8, 0, false, 3>"; rc = launch(attn_fwd_kernel<NW, 0, false, 3>); }
   else { g_last_attn_kernel = "attn_fwd_kernel<8, 0, false, 1>"; rc = launch(attn_fwd_kernel<NW, 0, false, 1>); }
   if (rc != LCV_OK) return rc;

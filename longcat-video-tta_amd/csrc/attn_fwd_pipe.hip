@@ -49,49 +49,10 @@ struct AttnFwdPipeParams {
   int64_t q_sb, q_sn, q_sh, k_sb, k_sn, k_sh, v_sb, v_sn, v_sh, o_sb, o_sn, o_sh;
   float scale;
   int gx, xcd_remap;
-  int prio_mode;   // A/B knob (LCV_ATTN_PIPE_PRIO): how the two waves of a SIMD take turns in the issue arbitration
+  int prio_mode;   // how the two waves of a SIMD take turns in the issue arbitration (0 = none; the lab variants measured no gain)
 };
 
 #define PIPE_RESCALE_THR 6.0f
-
-// Lab builds only (scratch/attn_lab/build_pipe.sh; results are wrong, only the clock is read): leave one class of instructions out
-// of the steady loop to price it.  The product never defines any of these.
-#if defined(LCV_PIPE_NO_KREAD)
-#define PIPE_LAB_KREAD(i) false
-#elif defined(LCV_PIPE_HALF_KREAD)
-#define PIPE_LAB_KREAD(i) (((i) & 2) == 0)
-#else
-#define PIPE_LAB_KREAD(i) true
-#endif
-#if defined(LCV_PIPE_NO_VREAD)
-#define PIPE_LAB_VREAD(j) false
-#elif defined(LCV_PIPE_HALF_VREAD)
-#define PIPE_LAB_VREAD(j) (((j) & 1) == 0)
-#else
-#define PIPE_LAB_VREAD(j) true
-#endif
-
-// Diagnostic build only (scratch/attn_lab/build_pipe.sh defines LCV_ATTN_STAMPS; the product never does): s_memtime stamps of
-// waves 0 and 4 of one block at five points of eight consecutive iterations, written to a buffer nothing else reads.
-#ifdef LCV_ATTN_STAMPS
-__device__ unsigned long long* g_pipe_dbg = nullptr;
-__device__ int g_pipe_dbg_block = 0;
-#define PIPE_STAMP(id)                                                                                      \
-  if (dbg_on && t >= 200 && t < 208) {                                                                      \
-    unsigned long long t_;                                                                                  \
-    __builtin_amdgcn_sched_barrier(0);                                                                      \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                              \
-    __builtin_amdgcn_sched_barrier(0);                                                                      \
-    /* parked in the last 32 KiB of LDS (no vector-memory traffic, so the loop's own vmcnt waits see nothing of it) */ \
-    if (lane == 0) *reinterpret_cast<AS3P unsigned long long*>(lds + 81920 + wave * 2048 + ((t - 200) * 8 + (id)) * 8) = t_; \
-  }
-extern "C" void attn_pipe_set_stamps(unsigned long long* buf, int block) {
-  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pipe_dbg), &buf, sizeof(buf));
-  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pipe_dbg_block), &block, sizeof(block));
-}
-#else
-#define PIPE_STAMP(id)
-#endif
 
 __device__ __forceinline__ float pipe_half_max(float v) {
   float a = v, b = v;
@@ -157,9 +118,6 @@ __global__ __launch_bounds__(512) void attn_fwd_pipe_kernel(const AttnFwdPipePar
     }
   };
   if (p.prio_mode == 3 && hi_half) __builtin_amdgcn_s_setprio(1);
-#ifdef LCV_ATTN_STAMPS
-  const bool dbg_on = g_pipe_dbg != nullptr && (int)blockIdx.x == g_pipe_dbg_block && (wave == 0 || wave == 4);
-#endif
   const int nt_ = (int)((p.Nk + 63) / 64);
   const bf16_t* kbase = p.k + b * p.k_sb + (int64_t)head * p.k_sh;
   const bf16_t* vbase = p.v + b * p.v_sb + (int64_t)head * p.v_sh;
@@ -362,7 +320,6 @@ __global__ __launch_bounds__(512) void attn_fwd_pipe_kernel(const AttnFwdPipePar
     const bool has_v2 = t + 2 < nt;
     const int v_delta = next_v_slot();                // v_slot == t % 3 from here on
     const int v_dst = V_REGION + ((v_slot == 0) ? 2 : v_slot - 1) * TILE;   // slot (t + 2) % 3
-    PIPE_STAMP(0)
     phase_prio(1);
     float psum = 0.f;
     float ex[32];      // P(t) in fp32, element order of SC
@@ -371,8 +328,8 @@ __global__ __launch_bounds__(512) void attn_fwd_pipe_kernel(const AttnFwdPipePar
     // ---------------- phase 1: 16 score MFMAs of tile t+1; exp2 / sums / packing of elements 0..23 of tile t ----------------
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      if (i + PD < 16 && PIPE_LAB_KREAD(i + PD)) kfr[(i + PD) % RING] = read_k(kb, i + PD);
-      if (i >= 16 - PD && PIPE_LAB_VREAD(i - (16 - PD))) vfr[i - (16 - PD)] = read_v(i - (16 - PD));   // first fragments of V(t) (landed since the last barrier)
+      if (i + PD < 16) kfr[(i + PD) % RING] = read_k(kb, i + PD);
+      if (i >= 16 - PD) vfr[i - (16 - PD)] = read_v(i - (16 - PD));   // first fragments of V(t) (landed since the last barrier)
       if (i == 0) {
         // both chains' first MFMAs in ONE statement, D != C (hipcc would pick the tied form and copy 16 registers per chain):
         // the resident -m_run tuple is read as C and survives
@@ -388,7 +345,6 @@ __global__ __launch_bounds__(512) void attn_fwd_pipe_kernel(const AttnFwdPipePar
       // exps of this gap: elements [e_lo, e_hi); the sums and packs trail one gap behind
       const int e_lo = (3 * i + 1) / 2, e_hi = (3 * (i + 1) + 1) / 2;
       const int a_lo = i ? (3 * (i - 1) + 1) / 2 : 0, a_hi = i ? e_lo : 0;
-#ifndef LCV_PIPE_NO_VALU
 #pragma unroll
       for (int j = 0; j < 24; ++j)
         if (j >= e_lo && j < e_hi) ex[j] = g_exp2(SC(c0, c1, j));
@@ -398,42 +354,30 @@ __global__ __launch_bounds__(512) void attn_fwd_pipe_kernel(const AttnFwdPipePar
           psum = (j == 0) ? ex[0] : g_add(psum, ex[j]);
           if (j & 1) pw[j >> 1] = g_pack(ex[j - 1], ex[j]);
         }
-#else
-      if (i == 0) {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) asm volatile("" : "=v"(pw[j]));
-        (void)e_lo; (void)e_hi; (void)a_lo; (void)a_hi;
-      }
-#endif
       SCHED_FENCE();
     }
-    PIPE_STAMP(1)
     if (t + 1 == nt - 1 && ragged) mask_last(n0, n1);   // scalar branch, taken once
     // the one barrier: K(t+2) and V(t+1) (requested in phase 2 of iteration t-1) are in LDS for every wave; every wave has
     // finished reading K(t+1) (phase 1) and V(t-1) (phase 2 of iteration t-1)
     dma_wait_and_barrier();
     phase_prio(2);
-    PIPE_STAMP(2)
     // ---------------- phase 2: 16 PV MFMAs of tile t; the rest of P(t); row max of S(t+1); next requests and fragments ------
     float mxa = 0.f, mxb = 0.f, mx = 0.f;
     SCHED_FENCE();
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-      if (j + PD < 16 && PIPE_LAB_VREAD(j + PD)) vfr[(j + PD) % RING] = read_v(j + PD);
-      if (j >= 16 - PD && PIPE_LAB_KREAD(j - (16 - PD))) kfr[j - (16 - PD)] = read_k(kb_next, j - (16 - PD));   // first fragments of K(t+2) (unused after the last one)
+      if (j + PD < 16) vfr[(j + PD) % RING] = read_v(j + PD);
+      if (j >= 16 - PD) kfr[j - (16 - PD)] = read_k(kb_next, j - (16 - PD));   // first fragments of K(t+2) (unused after the last one)
       const int kk = j >> 2;
       const u32x4 pbw = {pw[4 * kk], pw[4 * kk + 1], pw[4 * kk + 2], pw[4 * kk + 3]};
       oacc[j & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[j % RING], __builtin_bit_cast(bf16x8, pbw), oacc[j & 3], 0, 0, 0);
       SCHED_FENCE();
       // the four LDS-DMA pieces of this iteration: K(t+3) into K(t+1)'s buffer, V(t+2) into V(t-1)'s slot (both free since
       // the barrier above); they are waited for at the next barrier, a whole iteration away
-#ifndef LCV_PIPE_NO_DMA
       if (j == 0 && has_k3) dma_one(KOP{}, I0{}, (PAR ^ 1) * TILE, t + 3);
       if (j == 1 && has_k3) dma_one(KOP{}, I1{}, (PAR ^ 1) * TILE, t + 3);
       if (j == 2 && has_v2) dma_one(VOP{}, I0{}, v_dst, t + 2);
       if (j == 3 && has_v2) dma_one(VOP{}, I1{}, v_dst, t + 2);
-#endif
-#ifndef LCV_PIPE_NO_VALU
       if (j == 0) {   // element 23 (exp'ed in the last gap of phase 1)
         psum = g_add(psum, ex[23]);
         pw[11] = g_pack(ex[22], ex[23]);
@@ -455,12 +399,9 @@ __global__ __launch_bounds__(512) void attn_fwd_pipe_kernel(const AttnFwdPipePar
       if (j == 3) mxb = g_max3(n1[1], n1[2], n1[3]);
       if (j > 3 && j < 10) mxb = g_max3(mxb, n1[2 * (j - 2)], n1[2 * (j - 2) + 1]);
       if (j == 10) mx = pipe_half_max(g_max3(mxa, mxb, mxb));   // + the partner half's keys (one v_permlane32_swap)
-#endif
       SCHED_FENCE();
     }
-    PIPE_STAMP(3)
     settle(n0, n1, mx, false);
-    PIPE_STAMP(4)
   };
 
   // last tile: nothing left to overlap with; (c0, c1) hold S(nt - 1), settled; its V tile landed before the last barrier
@@ -499,11 +440,6 @@ __global__ __launch_bounds__(512) void attn_fwd_pipe_kernel(const AttnFwdPipePar
     else final_tile(sa0, sa1);
   }
 
-#ifdef LCV_ATTN_STAMPS
-  if (dbg_on && lane == 0)
-    for (int i = 0; i < 64; ++i)
-      g_pipe_dbg[(wave ? 256 : 0) + i] = *reinterpret_cast<AS3P unsigned long long*>(lds + 81920 + wave * 2048 + i * 8);
-#endif
   // ---- epilogue ----
   const float l_tot = pipe_half_sum(l_run);
   const float inv = 1.0f / l_tot;
@@ -539,20 +475,13 @@ int attn_fwd_pipe_launch(const void* q, const void* k, const void* v, void* o, f
   const unsigned gx = (unsigned)((Nq + 255) / 256);
   p.gx = (int)gx;
   p.xcd_remap = (xcd_ok && (B * H) % 8 == 0 && gx >= 8) ? 1 : 0;
-  const char* pm = getenv("LCV_ATTN_PIPE_PRIO");
-  p.prio_mode = pm ? pm[0] - '0' : 0;
-#ifdef LCV_ATTN_STAMPS
-  const size_t lds = 81920 + 8 * 2048;
-#else
+  p.prio_mode = 0;
   const size_t lds = 5 * 64 * 256;   // K x2, V x3
-#endif
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)attn_fwd_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+  // (function-local static: initialised once, thread-safe)
+  static const bool attr_ok = !(hipFuncSetAttribute((const void*)attn_fwd_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess);
+  if (!attr_ok) {
       lcv_set_error("attn_fwd: cannot raise dynamic LDS");
       return LCV_EDEVICE;
-    }
-    attr_set = true;
   }
   const dim3 grid = p.xcd_remap ? dim3(gx * (unsigned)(H * B)) : dim3(gx, (unsigned)H, (unsigned)B);
   hipLaunchKernelGGL(attn_fwd_pipe_kernel, grid, dim3(512), lds, s, p);

@@ -41,36 +41,6 @@ struct AttnFwdW64Params {
 
 #define W64_RESCALE_THR 6.0f
 
-// Lab builds only (scratch/attn_lab/build_w64.sh ablation; results are wrong, only the clock is read).  The product defines none.
-#ifdef LCV_W64_NO_KREAD
-#define W64_LAB_KREAD false
-#else
-#define W64_LAB_KREAD true
-#endif
-#ifdef LCV_W64_NO_VREAD
-#define W64_LAB_VREAD false
-#else
-#define W64_LAB_VREAD true
-#endif
-
-#ifdef LCV_ATTN_STAMPS
-__device__ unsigned long long* g_w64_dbg = nullptr;
-__device__ int g_w64_dbg_block = 0;
-#define W64_STAMP(id)                                                                                       \
-  if (dbg_on && t >= 200 && t < 208) {                                                                      \
-    unsigned long long t_;                                                                                  \
-    __builtin_amdgcn_sched_barrier(0);                                                                      \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                              \
-    __builtin_amdgcn_sched_barrier(0);                                                                      \
-    if (lane_now() == 0) *reinterpret_cast<AS3W unsigned long long*>(lds + 81920 + wave * 2048 + ((t - 200) * 8 + (id)) * 8) = t_; \
-  }
-extern "C" void attn_w64_set_stamps(unsigned long long* buf, int block) {
-  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_w64_dbg), &buf, sizeof(buf));
-  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_w64_dbg_block), &block, sizeof(block));
-}
-#else
-#define W64_STAMP(id)
-#endif
 
 __device__ __forceinline__ float w64_half_max(float v) {
   float a = v, b = v;
@@ -135,9 +105,6 @@ __global__ __launch_bounds__(256) void attn_fwd_w64_kernel(const AttnFwdW64Param
   }
   const int64_t q0 = (int64_t)qb * 256 + wave * 64;
   auto lane_now = []() -> int { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); };
-#ifdef LCV_ATTN_STAMPS
-  const bool dbg_on = g_w64_dbg != nullptr && (int)blockIdx.x == g_w64_dbg_block && (wave == 0 || wave == 2);
-#endif
   const int nt = (int)((p.Nk + 63) / 64);
   const bool ragged = (p.Nk & 63) != 0;
   const char* kbase_u = lcv_uniform_ptr(p.k + b * p.k_sb + (int64_t)head * p.k_sh);
@@ -351,7 +318,6 @@ __global__ __launch_bounds__(256) void attn_fwd_w64_kernel(const AttnFwdW64Param
     const bool has_v2 = STEADY || t + 2 < nt;
     const int v_delta = next_v_slot();                // v_slot == t % 3 from here on
     const int v_dst = V_REGION + ((v_slot == 0) ? 2 : v_slot - 1) * TILE;   // slot (t + 2) % 3
-    W64_STAMP(0)
     f32x2w psum[2];       // row sums of P(t), even / odd elements apart (v_pk_add_f32: one instruction per pair)
     f32x2w ex[2][16];     // P(t) in fp32: pair m = elements (2m, 2m + 1)
     unsigned pw[2][16];   // P(t) as packed bf16 pairs: word m = elements (2m, 2m + 1)
@@ -361,8 +327,8 @@ __global__ __launch_bounds__(256) void attn_fwd_w64_kernel(const AttnFwdW64Param
     for (int i = 0; i < 32; ++i) {
       const int f = i >> 1, nb = i & 1;               // fragment f = (k-step f >> 1, key block f & 1) feeds MFMAs 2 f, 2 f + 1
       if (nb == 0) {
-        if (f + PD < 16 && W64_LAB_KREAD) kfr[(f + PD) % RING] = read_k(kb, f + PD);
-        if (f >= 16 - PD && W64_LAB_VREAD) vfr[f - (16 - PD)] = read_v(f - (16 - PD));   // first fragments of V(t) (landed since the last barrier)
+        if (f + PD < 16) kfr[(f + PD) % RING] = read_k(kb, f + PD);
+        if (f >= 16 - PD) vfr[f - (16 - PD)] = read_v(f - (16 - PD));   // first fragments of V(t) (landed since the last barrier)
       }
       if (f < 2) {
         if (STEADY && i >= 1) mfma_s_first<false>(n[f & 1][nb], minit[nb], kfr[f % RING], qf[nb][0]);
@@ -377,12 +343,6 @@ __global__ __launch_bounds__(256) void attn_fwd_w64_kernel(const AttnFwdW64Param
       // exps of this gap: indices [e_lo, e_hi) of 48 (index -> query block idx & 1, element idx >> 1); sums / packs trail one gap
       const int e_lo = (3 * i + 1) / 2, e_hi = (3 * (i + 1) + 1) / 2;
       const int a_lo = i ? (3 * (i - 1) + 1) / 2 : 0, a_hi = i ? e_lo : 0;
-#ifdef LCV_W64_NO_VALU
-      if (i == 0) {
-#pragma unroll
-        for (int m = 0; m < 16; ++m) asm volatile("" : "=v"(pw[0][m]), "=v"(pw[1][m]));
-      }
-#else
 #pragma unroll
       for (int u = 0; u < 2; ++u) {                   // (at most two per gap; fixed trip count so that the loop unrolls)
         const int x = e_lo + u;
@@ -400,17 +360,14 @@ __global__ __launch_bounds__(256) void attn_fwd_w64_kernel(const AttnFwdW64Param
           }
         }
       }
-#endif
       SCHED_FENCE();
     }
-    W64_STAMP(1)
     if constexpr (!STEADY) {
       fence_s(n);
       if (t + 1 == nt - 1 && ragged) mask_last(n);   // scalar branch, taken once
     }
     // the one barrier: K(t+2) and V(t+1) are in LDS for every wave; every wave has finished reading K(t+1) and V(t-1)
     dma_wait_and_barrier();
-    W64_STAMP(2)
     // ---------------- phase 2: 32 PV MFMAs of tile t; the rest of P(t); row max of S(t+1); next requests and fragments --------
     float mxa[2] = {0.f, 0.f}, mxb[2] = {0.f, 0.f}, mxh[2] = {0.f, 0.f};
     bool need[2] = {false, false};
@@ -419,8 +376,8 @@ __global__ __launch_bounds__(256) void attn_fwd_w64_kernel(const AttnFwdW64Param
     for (int j = 0; j < 32; ++j) {
       const int g = j >> 1, nb = j & 1;               // fragment g = (k-step g >> 2, dim block g & 3) feeds MFMAs 2 g, 2 g + 1
       if (nb == 0) {
-        if (g + PD < 16 && W64_LAB_VREAD) vfr[(g + PD) % RING] = read_v(g + PD);
-        if (g >= 16 - PD && W64_LAB_KREAD) kfr[g - (16 - PD)] = read_k(kb_next, g - (16 - PD));   // first fragments of K(t+2)
+        if (g + PD < 16) vfr[(g + PD) % RING] = read_v(g + PD);
+        if (g >= 16 - PD) kfr[g - (16 - PD)] = read_k(kb_next, g - (16 - PD));   // first fragments of K(t+2)
       }
       const int kk = g >> 2;
       const u32x4 pbw = {pw[nb][4 * kk], pw[nb][4 * kk + 1], pw[nb][4 * kk + 2], pw[nb][4 * kk + 3]};
@@ -429,14 +386,11 @@ __global__ __launch_bounds__(256) void attn_fwd_w64_kernel(const AttnFwdW64Param
       SCHED_FENCE();
       // the eight LDS-DMA requests of this iteration: K(t+3) into K(t+1)'s buffer, V(t+2) into V(t-1)'s slot (both free since the
       // barrier above); waited for at the next barrier, a whole iteration away
-#ifndef LCV_W64_NO_DMA
       if (j % W64_DMA_STRIDE == 0 && j / W64_DMA_STRIDE < 8) {
         const int dj = j / W64_DMA_STRIDE;
         if (dj < 4) { if (has_k3) dma_one(KOP, dj & 3, (PAR ^ 1) * TILE, t + 3, STEADY); }
         else { if (has_v2) dma_one(VOP, dj & 3, v_dst, t + 2, STEADY); }
       }
-#endif
-#ifndef LCV_W64_NO_VALU
       // row max of S(t+1) first (gaps 0..15: per query block 16 max3 over its 32 values, two chains of 8), then the exchange with
       // the partner half and the ballot in gaps 16..19: nothing but two scalar branches is left behind the phase
       if (j < 16) {
@@ -473,13 +427,10 @@ __global__ __launch_bounds__(256) void attn_fwd_w64_kernel(const AttnFwdW64Param
       }
       if (j == 24 || j == 25) psum[j & 1][0] = w_add(psum[j & 1][0], psum[j & 1][1]);
       if (j == 26 || j == 27) l_run[j & 1] = w_add(l_run[j & 1], psum[j & 1][0]);
-#endif
       SCHED_FENCE();
     }
-    W64_STAMP(3)
     settle(n, std::integral_constant<int, 0>{}, mxh[0], false, need[0]);
     settle(n, std::integral_constant<int, 1>{}, mxh[1], false, need[1]);
-    W64_STAMP(4)
   };
 
   // last tile: nothing left to overlap with; c = S(nt - 1), settled; its V tile landed before the last barrier
@@ -534,11 +485,6 @@ __global__ __launch_bounds__(256) void attn_fwd_w64_kernel(const AttnFwdW64Param
     else final_tile(sa);
   }
 
-#ifdef LCV_ATTN_STAMPS
-  if (dbg_on && lane_now() == 0)
-    for (int i = 0; i < 64; ++i)
-      g_w64_dbg[(wave ? 256 : 0) + i] = *reinterpret_cast<AS3W unsigned long long*>(lds + 81920 + wave * 2048 + i * 8);
-#endif
   // ---- epilogue ----
   const int lane_l = lane_now();
   const int r_l = lane_l & 31, h_l = lane_l >> 5;
@@ -578,18 +524,12 @@ int attn_fwd_w64_launch(const void* q, const void* k, const void* v, void* o, fl
   const unsigned gx = (unsigned)((Nq + 255) / 256);
   p.gx = (int)gx;
   p.xcd_remap = (xcd_ok && (B * H) % 8 == 0 && gx >= 8) ? 1 : 0;
-#ifdef LCV_ATTN_STAMPS
-  const size_t lds = 81920 + 8 * 2048;
-#else
   const size_t lds = 5 * 64 * 256;   // K x2, V x3
-#endif
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)attn_fwd_w64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+  // (function-local static: initialised once, thread-safe)
+  static const bool attr_ok = !(hipFuncSetAttribute((const void*)attn_fwd_w64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess);
+  if (!attr_ok) {
       lcv_set_error("attn_fwd_w64: cannot raise dynamic LDS");
       return LCV_EDEVICE;
-    }
-    attr_set = true;
   }
   const dim3 grid = p.xcd_remap ? dim3(gx * (unsigned)(H * B)) : dim3(gx, (unsigned)H, (unsigned)B);
   hipLaunchKernelGGL(attn_fwd_w64_kernel, grid, dim3(256), lds, s, p);

@@ -386,17 +386,15 @@ static int launch_conv_rows(GemmParams& p, hipStream_t s) {
   const int64_t n_tiles = (p.M / p.cv_W) * tiles_per_row;
   LCV_CHECK_ARG(n_tiles < (int64_t(1) << 31), "conv3d: %ld row tiles", (long)n_tiles);
   auto kern = conv_rows_kernel<WM, WN, TM, TN, EPI>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES) != hipSuccess) {
+  // (function-local static: initialised once, thread-safe)
+  static const bool attr_ok = !(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES) != hipSuccess);
+  if (!attr_ok) {
       lcv_set_error("conv3d: cannot raise dynamic LDS to %d", Cfg::LDS_BYTES);
       return LCV_EDEVICE;
-    }
-    attr_set = true;
   }
   // one workgroup per CU, a multiple of 8 (XCDs); fewer when there are fewer tiles
   int grid = 256;
-  { const char* e = getenv("LCV_CONV_ROWS_GRID"); if (e && atoi(e) >= 8) grid = atoi(e) / 8 * 8; }
+  { const char* e = lcv_knob("LCV_CONV_ROWS_GRID"); if (e && atoi(e) >= 8) grid = atoi(e) / 8 * 8; }
   if ((int64_t)grid > (n_tiles + 7) / 8 * 8) grid = (int)((n_tiles + 7) / 8 * 8);
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3((8 + CONV_ROWS_LOADERS) * 64), Cfg::LDS_BYTES, s, p, tiles_per_row, (int)n_tiles);   // 8 MFMA waves + the loaders
   LCV_LAUNCH_CHECK("conv_rows");
@@ -406,7 +404,7 @@ static int launch_conv_rows(GemmParams& p, hipStream_t s) {
 // Which convolutions take the row-tile kernel: stride 1, at most 3 taps along w, 96-channel slices, Cout <= 96, and rows long
 // enough that the last (partial) tile of a row does not dominate.
 static bool conv_rows_applies(const GemmParams& p, int64_t cin) {
-  if (getenv("LCV_CONV_ROWS") && atoi(getenv("LCV_CONV_ROWS")) == 0) return false;
+  if (lcv_knob("LCV_CONV_ROWS") && atoi(lcv_knob("LCV_CONV_ROWS")) == 0) return false;
   if (p.cv_st != 1 || p.cv_sh != 1 || p.cv_sw != 1) return false;
   if (cin % 96 != 0 || p.N > 96 || p.cv_kw > 3) return false;
   const int slices = (int)(cin / 96);

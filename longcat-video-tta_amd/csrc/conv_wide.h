@@ -154,13 +154,11 @@ static int launch_conv_wide(GemmParams& p, hipStream_t s) {
   p.tiles_n = (int)(p.N / 192);
   const size_t lds = 2 * (256 + 192) * 128;
   auto kern = conv_wide_kernel<EPI>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+  // (function-local static: initialised once, thread-safe)
+  static const bool attr_ok = !(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess);
+  if (!attr_ok) {
       lcv_set_error("conv3d: cannot raise dynamic LDS to %zu", lds);
       return LCV_EDEVICE;
-    }
-    attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(1024), lds, s, p);   // 8 MFMA + 8 loader waves
   LCV_LAUNCH_CHECK("conv_wide");

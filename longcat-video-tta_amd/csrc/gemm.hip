@@ -670,19 +670,7 @@ __global__ __launch_bounds__(WR* WC * 64) void gemm16_nt_kernel(const GemmParams
 //   RAW: the wait of phase p (before its first barrier) retires everything but the 4 newest half-tiles, which always
 //        includes every slot phase p+1 reads; the reader passes at least one more barrier than any waiter.
 // ---------------------------------------------------------------------------
-#ifdef LCV_GEMM_STAMPS  // scratch/gemm_lab only: s_memtime at every barrier arrival / release of one workgroup
-__device__ unsigned long long* g_gdbg = nullptr;
-#define GSTAMP()                                                                                      \
-  do {                                                                                                \
-    if (gdbg_on && gdbg_n < 512) {                                                                    \
-      const unsigned long long tnow__ = __builtin_amdgcn_s_memtime();                                 \
-      if (lane == 0) gdbg_p[(wave ? 512 : 0) + gdbg_n] = tnow__;                                      \
-      ++gdbg_n;                                                                                       \
-    }                                                                                                 \
-  } while (0)
-#else
 #define GSTAMP() do {} while (0)
-#endif
 
 #include "gemm_fast_epilogue.h"
 
@@ -720,11 +708,6 @@ __global__ __launch_bounds__(512) void gemm8p_nt_kernel(const GemmParams p) {
     k_off = (int)(blockIdx.x / (unsigned)p.vid_count) * p.nk_split;
     nk = min(p.nk_split, nk - k_off);          // >= 2 (host-checked)
   }
-#ifdef LCV_GEMM_STAMPS
-  int gdbg_n = 0;
-  unsigned long long* const gdbg_p = g_gdbg;
-  const bool gdbg_on = gdbg_p != nullptr && blockIdx.x == 100 && (wave == 0 || wave == 4);
-#endif
 
   // ---- LDS-DMA roles: instruction t of wave w fills slot rows 8 (2 w + t) .. +8; lane -> row (lane >> 3), 16-B position
   // (lane & 7) which holds logical chunk (lane & 7) ^ ((row >> 1) & 7).  Per-lane state is the (clamped) global row of
@@ -1051,7 +1034,7 @@ extern "C" int lcv_gemm_set_workspace(void* ws, int64_t bytes) {
 // -23 % when split 5 ways - the partial sums of a fat tail cost more than its idle CUs, so only thin tails qualify.
 static int choose_tail_split(int t, int nk, int64_t ws_bytes) {
   if (t <= 0 || t > 32) return 1;
-  const char* e = getenv("LCV_GEMM_SPLITK_TAIL");
+  const char* e = lcv_knob("LCV_GEMM_SPLITK_TAIL");
   if (e && e[0] == '0') return 1;
   int best_s = 1;
   double best = 1.0;
@@ -1070,33 +1053,29 @@ static int launch_gemm8p(GemmParams& p, hipStream_t s) {
   p.tiles_m = (int)((p.M + 255) / 256);
   // tile rows per group of the tile order (A/B knob LCV_GEMM_GROUP_M): 6 measured best for the persistent kernel at the K3
   // projection shapes (4, 6, 8, 16 -> 1267, 1285, 1240, 1172 TF/s on the qkv GEMM, in one process)
-  { const char* ge = getenv("LCV_GEMM_GROUP_M"); p.group_m = ge ? atoi(ge) : 6; if (p.group_m < 1) p.group_m = 6; }
+  { const char* ge = lcv_knob("LCV_GEMM_GROUP_M"); p.group_m = ge ? atoi(ge) : 6; if (p.group_m < 1) p.group_m = 6; }
   p.tiles_n = (int)((p.N + 255) / 256);
   const size_t lds = 2 * 65536;
   auto kern = gemm8p_nt_kernel<EPI, PERSIST>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+  // (function-local static: initialised once, thread-safe)
+  static const bool attr_ok = !(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess);
+  if (!attr_ok) {
       lcv_set_error("gemm_nt: cannot raise dynamic LDS to %zu", lds);
       return LCV_EDEVICE;
-    }
-    attr_set = true;
   }
   const int ntiles = p.tiles_m * p.tiles_n;
   p.vid_begin = 0; p.vid_count = ntiles; p.splitk = 1; p.nk_split = 0; p.ws = nullptr;
-  { const char* fe = getenv("LCV_GEMM_FAST_EPI"); p.fast_epi = (fe && fe[0] == '0') ? 0 : 1; }
+  { const char* fe = lcv_knob("LCV_GEMM_FAST_EPI"); p.fast_epi = (fe && fe[0] == '0') ? 0 : 1; }
   if (PERSIST && ntiles > 256 && g_gemm_ws != nullptr) {
     const int t = ntiles % 256, nk = p.nk1 + p.nk2;
     const int sk = choose_tail_split(t, nk, g_gemm_ws_bytes);
     if (sk > 1) {
       auto skern = gemm8p_nt_kernel<LCV_EPI_NONE, false, true>;
-      static bool sattr_set = false;
-      if (!sattr_set) {
-        if (hipFuncSetAttribute((const void*)skern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      // (function-local static: initialised once, thread-safe)
+      static const bool sattr_ok = !(hipFuncSetAttribute((const void*)skern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess);
+      if (!sattr_ok) {
           lcv_set_error("gemm_nt: cannot raise dynamic LDS to %zu", lds);
           return LCV_EDEVICE;
-        }
-        sattr_set = true;
       }
       p.vid_count = ntiles - t;                           // full rounds: every CU busy to the end
       hipLaunchKernelGGL(kern, dim3(256), dim3(512), lds, s, p);
@@ -1124,13 +1103,11 @@ static int launch_conv8p(GemmParams& p, hipStream_t s) {
   p.tiles_n = (int)((p.N + 255) / 256);
   const size_t lds = 2 * 65536;
   auto kern = gemm8p_nt_kernel<EPI, true, false, true>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+  // (function-local static: initialised once, thread-safe)
+  static const bool attr_ok = !(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess);
+  if (!attr_ok) {
       lcv_set_error("conv3d: cannot raise dynamic LDS to %zu", lds);
       return LCV_EDEVICE;
-    }
-    attr_set = true;
   }
   const int ntiles = p.tiles_m * p.tiles_n;
   p.vid_begin = 0; p.vid_count = ntiles; p.splitk = 1; p.nk_split = 0; p.ws = nullptr;
@@ -1149,17 +1126,15 @@ static int launch_gemm4k(GemmParams& p, hipStream_t s) {
   p.tiles_m = (int)((p.M + 255) / 256);
   // tile rows per group of the XCD-contiguous tile order: 3 measured best for this kernel (1 ... 64 swept in one process at the
   // qkv / w13 / proj shapes, profiles/r04_gemm_ab.md: 1435 / 1358 / 1411 TF/s at 3, 1398 / 1353 / 1420 at 6, 1254 / 1251 / 1275 at 16)
-  { const char* ge = getenv("LCV_GEMM_GROUP_M"); p.group_m = ge ? atoi(ge) : 3; if (p.group_m < 1) p.group_m = 3; }
+  { const char* ge = lcv_knob("LCV_GEMM_GROUP_M"); p.group_m = ge ? atoi(ge) : 3; if (p.group_m < 1) p.group_m = 3; }
   p.tiles_n = (int)((p.N + 255) / 256);
   const size_t lds = 2 * 65536;
   auto kern = gemm4k_nt_kernel<EPI>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+  // (function-local static: initialised once, thread-safe)
+  static const bool attr_ok = !(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess);
+  if (!attr_ok) {
       lcv_set_error("gemm_nt: cannot raise dynamic LDS to %zu", lds);
       return LCV_EDEVICE;
-    }
-    attr_set = true;
   }
   const int ntiles = p.tiles_m * p.tiles_n;
   p.vid_begin = 0; p.vid_count = ntiles; p.splitk = 1; p.nk_split = 0; p.ws = nullptr;
@@ -1177,13 +1152,11 @@ static int launch_gemm16(GemmParams& p, hipStream_t s) {
   const size_t lds = NST * Cfg::STAGE_BYTES;
   static_assert(NST * Cfg::STAGE_BYTES <= 163840, "gemm16: LDS image");
   auto kern = gemm16_nt_kernel<BM, BN, WR, WC, EPI, CONV, NST>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+  // (function-local static: initialised once, thread-safe)
+  static const bool attr_ok = !(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess);
+  if (!attr_ok) {
       lcv_set_error("gemm_nt: cannot raise dynamic LDS to %zu", lds);
       return LCV_EDEVICE;
-    }
-    attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(Cfg::NT), lds, s, p);
   LCV_LAUNCH_CHECK(CONV ? "conv16_igemm" : "gemm16_nt");
@@ -1198,13 +1171,11 @@ static int launch_gemm(GemmParams& p, hipStream_t s) {
   p.tiles_n = (int)((p.N + BN - 1) / BN);
   const size_t lds = 2 * Cfg::STAGE_BYTES;
   auto kern = gemm_nt_kernel<BM, BN, WR, WC, EPI, CONV>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+  // (function-local static: initialised once, thread-safe)
+  static const bool attr_ok = !(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess);
+  if (!attr_ok) {
       lcv_set_error("gemm_nt: cannot raise dynamic LDS to %zu", lds);
       return LCV_EDEVICE;
-    }
-    attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(Cfg::NT), lds, s, p);
   LCV_LAUNCH_CHECK(CONV ? "conv_igemm" : "gemm_nt");
@@ -1216,7 +1187,7 @@ static int dispatch_tile(GemmParams& p, hipStream_t s) {
   // v_mfma_f32_16x16x32_bf16 kernels by default: 256x256 tiles for the big token-side projections (measured
   // 1062-1118 TF/s at K3 shapes vs 982-1004 for the 32x32x16 kernel), 128x128 for small M or N.
   // LCV_GEMM_TILE = 6 | 7 forces 256 / 128 (16x16x32); 2 | 1 the same tiles on the 32x32x16 kernel (A/B runs, tests).
-  const char* force = getenv("LCV_GEMM_TILE");
+  const char* force = lcv_knob("LCV_GEMM_TILE");
   int mode = (p.M >= 2048 && p.N >= 1024) ? 6 : 7;
   // 8-phase ping-pong schedule on the same tile; its LDS-DMA sources are 32-bit byte offsets from the operand base
   const bool ok8 = p.nk1 >= 2 && (uint64_t)p.M * p.lda * 2 < (1ull << 32) && (uint64_t)p.N * p.ldw * 2 < (1ull << 32) &&
@@ -1250,10 +1221,10 @@ static int dispatch_conv(GemmParams& p, hipStream_t s) {
   // wide stages: the 8-phase kernel when its pipeline has K tiles to fill (>= 2)
   // wide stages.  LCV_CONV_8P=1: the 8-phase kernel with the gather in its A stream - bit-identical to the two-stage kernel and
   // no faster on the VAE's shapes (802 vs 816 TF/s on 192 -> 192 at 360 x 640), so it stays opt-in.
-  const char* e8 = getenv("LCV_CONV_8P");
+  const char* e8 = lcv_knob("LCV_CONV_8P");
   if (p.N >= 192 && p.nk1 >= 2 && e8 && e8[0] == '1') return launch_conv8p<EPI>(p, s);
   // Cout = 192 / 384: 192-column tiles instead of 256-column tiles of which a quarter multiplies padding
-  const char* e192 = getenv("LCV_CONV_N192");
+  const char* e192 = lcv_knob("LCV_CONV_N192");
   if (p.N >= 192 && p.N % 192 == 0 && !(e192 && e192[0] == '0')) {
     // LCV_CONV_N192=3: 192 x 192 tiles on a ring of three buffers with a counted wait - bit-identical and SLOWER (873 vs 919,
     // 952 vs 1011 TF/s): these kernels do not wait for the round trip of their requests
@@ -1344,12 +1315,12 @@ static int conv3d_impl(const void* x, const void* w, const void* bias, const voi
   hipStream_t s = (hipStream_t)stream;
   if (conv_rows_applies(p, Cin)) {
     p.cv_cpt = (int)(Cin / 96);
-    { const char* eo = getenv("LCV_CONV_ROWS_ORDER"); p.splitk = (eo && eo[0] == 'w') ? 1 : 0; }   // tile sequence (conv_rows.h)
+    { const char* eo = lcv_knob("LCV_CONV_ROWS_ORDER"); p.splitk = (eo && eo[0] == 'w') ? 1 : 0; }   // tile sequence (conv_rows.h)
     g_last_conv_kernel = p.N <= 16 ? "conv_rows<256x16>" : "conv_rows<256x96>";
     if (p.N <= 16) return resid ? launch_conv_rows<8, 1, 2, 1, LCV_EPI_GATE_RESIDUAL>(p, s) : launch_conv_rows<8, 1, 2, 1, LCV_EPI_NONE>(p, s);
     return resid ? launch_conv_rows<4, 2, 4, 3, LCV_EPI_GATE_RESIDUAL>(p, s) : launch_conv_rows<4, 2, 4, 3, LCV_EPI_NONE>(p, s);
   }
-  { const char* e8 = getenv("LCV_CONV_8P"); const char* e192 = getenv("LCV_CONV_N192");
+  { const char* e8 = lcv_knob("LCV_CONV_8P"); const char* e192 = lcv_knob("LCV_CONV_N192");
     g_last_conv_kernel = p.N < 192 ? "conv16_igemm<128x128>"
                          : (p.nk1 >= 2 && e8 && e8[0] == '1') ? "conv8p_igemm<256x256>"
                          : (p.N % 192 == 0 && !(e192 && e192[0] == '0')) ? ((e192 && e192[0] == '3') ? "conv16_igemm<192x192x3>" : (e192 && e192[0] == '2') ? "conv16_igemm<256x192>" : "conv_wide<256x192>")
@@ -1455,13 +1426,11 @@ extern "C" int lcv_linear_f32_smallm(const float* a, const void* w, const void* 
     const int cols_per_wave = 4;
     const unsigned grid = (unsigned)((N + 4 * cols_per_wave - 1) / (4 * cols_per_wave));
     auto kern = linear_f32_smallm_kernel<16>;
-    static bool attr_set = false;
-    if (!attr_set) {
-      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+    // (function-local static: initialised once, thread-safe)
+    static const bool attr_ok = !(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess);
+    if (!attr_ok) {
         lcv_set_error("linear_f32_smallm: cannot raise dynamic LDS");
         return LCV_EDEVICE;
-      }
-      attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a + m0 * K, (const bf16_t*)w, (const bf16_t*)bias,
                        out + m0 * N, Mc, N, (int)K, act_in, cols_per_wave);

@@ -38,6 +38,12 @@ void lcv_set_error(const char* fmt, ...);
     }                                                                      \
   } while (0)
 
+// ---- A/B knobs (host) ----
+// The launchers' LCV_* environment variables are read ONCE, when the library is first used, into a table in lib.hip (the list is
+// part of the documented interface: include/lcv_hip.h).  `lcv_knob(name)` returns the value or nullptr when it is unset;
+// `lcv_knobs_reload()` (C ABI) reads the environment again - for tests and A/B harnesses that flip a knob inside one process.
+const char* lcv_knob(const char* name);
+
 // ---- bf16 <-> f32 (device) ----
 __device__ __forceinline__ float bf2f(bf16_t u) {
   return __builtin_bit_cast(float, (unsigned int)u << 16);

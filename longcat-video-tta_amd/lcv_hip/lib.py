@@ -103,6 +103,10 @@ def load():
     lib.lcv_last_error.argtypes = []
     lib.lcv_attn_fwd_last_kernel.restype = c_char_p
     lib.lcv_attn_fwd_last_kernel.argtypes = []
+    lib.lcv_knobs_list.restype = c_char_p
+    lib.lcv_knobs_list.argtypes = []
+    lib.lcv_knobs_reload.restype = c_int           # a count, not a status
+    lib.lcv_knobs_reload.argtypes = []
     lib.lcv_conv3d_last_kernel.restype = c_char_p
     lib.lcv_conv3d_last_kernel.argtypes = []
     lib.lcv_tn_skinny_ws_bytes.restype = c_int64     # a size, not a status
@@ -117,6 +121,21 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def reload_knobs() -> int:
+    """The library reads its LCV_* A/B knobs once (include/lcv_hip.h); call this after changing one in os.environ."""
+    return load().lcv_knobs_reload()
+
+
+def set_knob(name: str, value) -> None:
+    """Set (or, with None, unset) an A/B knob in os.environ and make the library see it."""
+    if value is None:
+        os.environ.pop(name, None)
+    else:
+        os.environ[name] = str(value)
+    if _lib is not None:
+        _lib.lcv_knobs_reload()
 
 
 def call(name: str, *args):

@@ -4,6 +4,7 @@ on the four K3 projection shapes at M = 93 600.  argv[1] = "check" | "time" | "a
 import os, sys, torch
 sys.path.insert(0, "longcat-video-tta_amd"); sys.path.insert(0, ".")
 from lcv_hip import ops
+import lcv_hip.lib as L
 from lcv_hip.lib import LCV_EPI_GATE_RESIDUAL, LCV_EPI_SWIGLU
 dev = "cuda"; bf = torch.bfloat16
 what = sys.argv[1] if len(sys.argv) > 1 else "all"
@@ -15,7 +16,7 @@ def rn(*s, seed=0, scale=1.0, dtype=bf):
 
 
 def tile(t):
-    os.environ["LCV_GEMM_TILE"] = t
+    L.set_knob("LCV_GEMM_TILE", t)
 
 
 if what in ("check", "all"):

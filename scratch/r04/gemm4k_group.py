@@ -2,6 +2,7 @@
 import os, sys, torch
 sys.path.insert(0, "longcat-video-tta_amd"); sys.path.insert(0, ".")
 from lcv_hip import ops
+import lcv_hip.lib as L
 dev = "cuda"; bf = torch.bfloat16
 def rn(*s, seed=0, scale=1.0):
     g = torch.Generator().manual_seed(seed)
@@ -19,10 +20,10 @@ for (N, K, name) in ((12288, 4096, "qkv"), (22016, 4096, "w13"), (4096, 4096, "p
     a = rn(M, K, seed=11); w = rn(N, K, seed=12, scale=0.02); b = rn(N, seed=13)
     fl = 2 * M * N * K
     for t in ("k", "9"):
-        os.environ["LCV_GEMM_TILE"] = t
+        L.set_knob("LCV_GEMM_TILE", t)
         row = []
         for gm in ("1", "2", "3", "4", "6", "8", "12", "16", "32", "64"):
-            os.environ["LCV_GEMM_GROUP_M"] = gm
+            L.set_knob("LCV_GEMM_GROUP_M", gm)
             ms = timeit(lambda: ops.gemm_nt(a, w, b)); row.append(f"g{gm}: {fl / ms / 1e9:.0f}")
         print(f"{name} [{t}]: " + " | ".join(row), flush=True)
     del a, w; torch.cuda.empty_cache()

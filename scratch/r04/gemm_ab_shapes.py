@@ -4,6 +4,7 @@ K5 (96 720).  Prints ms and TF/s per (shape, kernel) and hipBLASLt for the plain
 import os, sys, torch
 sys.path.insert(0, "longcat-video-tta_amd"); sys.path.insert(0, ".")
 from lcv_hip import ops
+import lcv_hip.lib as L
 from lcv_hip.lib import LCV_EPI_GATE_RESIDUAL, LCV_EPI_SWIGLU
 dev = "cuda"; bf = torch.bfloat16
 def rn(*s, seed=0, scale=1.0, dtype=bf):
@@ -37,7 +38,7 @@ for M in Ms:
         res = {}
         for rnd in range(2):
             for t in ("9", "k"):
-                os.environ["LCV_GEMM_TILE"] = t
+                L.set_knob("LCV_GEMM_TILE", t)
                 ms = timeit(lambda: ops.gemm_nt(a, w, b, out=out, **kw))
                 row.append(f"[{t}] {ms:.3f} ms {fl / ms / 1e9:.0f}")
                 res[t] = out.clone()

@@ -3,6 +3,7 @@ kernel and hipBLASLt (torch), a few launches each.  argv: shape name (proj|qkv|w
 import os, sys, torch
 sys.path.insert(0, "longcat-video-tta_amd"); sys.path.insert(0, ".")
 from lcv_hip import ops
+import lcv_hip.lib as L
 dev = "cuda"; bf = torch.bfloat16
 SH = {"proj": (4096, 4096), "qkv": (12288, 4096), "w13": (22016, 4096), "w2": (4096, 11008)}
 name = sys.argv[1] if len(sys.argv) > 1 else "proj"
@@ -10,10 +11,10 @@ N, K = SH[name]
 M = 93600
 a = torch.randn(M, K, device=dev).to(bf); w = (torch.randn(N, K, device=dev) * 0.02).to(bf); b = torch.randn(N, device=dev).to(bf)
 for tile in ("9", "4", "k"):
-    os.environ["LCV_GEMM_TILE"] = tile
+    L.set_knob("LCV_GEMM_TILE", tile)
     for _ in range(6):
         ops.gemm_nt(a, w, b)
-os.environ.pop("LCV_GEMM_TILE")
+L.set_knob("LCV_GEMM_TILE", None)
 for _ in range(6):
     torch.nn.functional.linear(a, w, b)
 torch.cuda.synchronize()

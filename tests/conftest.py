@@ -25,6 +25,30 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+@pytest.fixture(autouse=True)
+def _library_knobs_follow_the_environment(monkeypatch):
+    """liblcv_hip.so reads its LCV_* A/B knobs once (include/lcv_hip.h).  Tests flip them with `monkeypatch.setenv`: re-read after
+    every such change, and at the start of every test (monkeypatch has restored the environment by then)."""
+    def reload():
+        lib = sys.modules.get("lcv_hip.lib")
+        if lib is not None and getattr(lib, "_lib", None) is not None:
+            lib._lib.lcv_knobs_reload()
+    reload()
+    setenv, delenv = monkeypatch.setenv, monkeypatch.delenv
+
+    def setenv_and_reload(name, value, *a, **k):
+        setenv(name, value, *a, **k)
+        if name.startswith("LCV_"):
+            reload()
+
+    def delenv_and_reload(name, *a, **k):
+        delenv(name, *a, **k)
+        if name.startswith("LCV_"):
+            reload()
+    monkeypatch.setenv, monkeypatch.delenv = setenv_and_reload, delenv_and_reload
+    yield
+
+
 def rel_l2(a, b):
     import torch
     a = a.detach().float().cpu()

@@ -30,8 +30,21 @@ def test_library_builds_and_exports_every_declared_symbol():
     so.lcv_version.restype = ctypes.c_int
     assert so.lcv_version() >= 1          # host-only call
     table = set(lib._SIGNATURES) | {"lcv_version", "lcv_last_error", "lcv_attn_fwd_last_kernel", "lcv_tn_skinny_ws_bytes",
-                                       "lcv_conv3d_last_kernel", "lcv_attn_bwd_ws_floats"}
+                                       "lcv_conv3d_last_kernel", "lcv_attn_bwd_ws_floats", "lcv_knobs_reload", "lcv_knobs_list"}
     assert set(names) == table, (set(names) ^ table)
+    # the A/B knobs: one table, read once, listed in the header (host-only calls); no source reads the environment itself
+    so.lcv_knobs_list.restype = ctypes.c_char_p
+    knobs = so.lcv_knobs_list().decode().split()
+    header = (ROOT / "include" / "lcv_hip.h").read_text()
+    assert len(knobs) >= 10 and all(k.startswith("LCV_") and k in header for k in knobs)
+    used = set()
+    for f in (ROOT / "longcat-video-tta_amd" / "csrc").glob("*.h*"):
+        if f.name != "lib.hip":
+            assert "getenv(" not in f.read_text(), f"{f.name} reads the environment itself"
+        used |= set(re.findall(r'lcv_knob\("(LCV_[A-Z0-9_]+)"\)', f.read_text()))
+    assert used == set(knobs), used ^ set(knobs)
+    so.lcv_knobs_reload.restype = ctypes.c_int
+    assert so.lcv_knobs_reload() >= 0
 
 
 def test_no_cpu_fallback():
