@@ -63,7 +63,7 @@ def test_attention_kernel_matches_oracle(B, S, H, nvalid):
     s = r(r(q @ k.transpose(2, 3)) + bias)
     s = s.masked_fill(mask[:, None, None, :] == 0, float("-inf"))
     ref = r(r(torch.softmax(s, -1)) @ v).transpose(1, 2).reshape(B, S, inner)
-    assert rel_l2(got, ref) < 4e-3, rel_l2(got, ref)
+    assert rel_l2(got, ref, bound=4e-3) < 4e-3, rel_l2(got, ref)
 
 
 @pytest.mark.parametrize("cfg,S,nvalid", [
@@ -85,7 +85,7 @@ def test_encoder_matches_oracle(cfg, S, nvalid):
     e, scale = rel_l2(out[0, :nvalid], ref[0, :nvalid]), rel_l2(ref[0, :nvalid], exact[0, :nvalid])
     print(f"HIP vs bf16 oracle {e:.2e}; bf16 oracle vs fp32 oracle {scale:.2e}")
     assert e < 2e-2
-    assert rel_l2(out[0, :nvalid], exact[0, :nvalid]) < 2.5 * scale + 5e-3
+    assert rel_l2(out[0, :nvalid], exact[0, :nvalid], bound=2.5) < 2.5 * scale + 5e-3
 
 
 def test_encoder_matches_transformers_bf16_cpu():

@@ -49,7 +49,7 @@ def test_conv_kernel_against_conv3d():
         else:
             y = F.pad(xn, (k[2] // 2, k[2] // 2, k[1] // 2, k[1] // 2, k[0] - 1, 0))
             ref = F.conv3d(y, wf, bf).permute(0, 2, 3, 4, 1)
-        assert rel_l2(got, ref) < 3e-3, (ci, co, k, up)
+        assert rel_l2(got, ref, bound=3e-3) < 3e-3, (ci, co, k, up)
 
 
 @pytest.mark.parametrize("ci,co,k,up,W,resid", [
@@ -104,8 +104,8 @@ def test_row_tile_conv_kernel(ci, co, k, up, W, resid, monkeypatch):
         ref = F.conv3d(y, wf, bf).permute(0, 2, 3, 4, 1)
     if resid:
         ref = r[..., :co].float() + ref.to(BF16).float()
-    assert rel_l2(got, ref) < 3e-3
-    assert rel_l2(got, old) < 3e-3 and not torch.equal(got, torch.zeros_like(got))
+    assert rel_l2(got, ref, bound=3e-3) < 3e-3
+    assert rel_l2(got, old, bound=3e-3) < 3e-3 and not torch.equal(got, torch.zeros_like(got))
 
 
 @pytest.mark.parametrize("T", [1, 3])
@@ -182,7 +182,7 @@ def test_wide_conv_kernel_many_tiles(ci, co, k, up, resid, monkeypatch):
         ref = F.conv3d(y, wf, bf).permute(0, 2, 3, 4, 1)
     if resid:
         ref = r[..., :co].float() + ref.to(BF16).float()
-    assert rel_l2(got, ref) < 3e-3
+    assert rel_l2(got, ref, bound=3e-3) < 3e-3
 
 
 def test_strided_conv_kernel_against_torch():
@@ -200,7 +200,7 @@ def test_strided_conv_kernel_against_torch():
         y = F.pad(x.float().permute(0, 1, 4, 2, 3).reshape(3, ci, H, W), (0, 1, 0, 1))
         ref = F.conv2d(y, conv.weight.float().cpu(), conv.bias.float().cpu(), stride=2)
         assert ref.shape[-2:] == (H // 2, W // 2)
-        assert rel_l2(got, ref.view(1, 3, co, H // 2, W // 2).permute(0, 1, 3, 4, 2)) < 3e-3
+        assert rel_l2(got, ref.view(1, 3, co, H // 2, W // 2).permute(0, 1, 3, 4, 2), bound=3e-3) < 3e-3
     ci = co = 64
     conv = _Conv(ci, co, (3, 1, 1), device="cuda", dtype=BF16)
     with torch.no_grad():
@@ -208,7 +208,7 @@ def test_strided_conv_kernel_against_torch():
     x = torch.randn(1, 9, 4, 5, ci, generator=g).to(BF16)
     got = vae._conv_strided(x.cuda(), conv, (2, 1, 1), (4, 4, 5)).float().cpu()
     ref = F.conv3d(x.float().permute(0, 4, 1, 2, 3), conv.weight.float().cpu(), conv.bias.float().cpu(), stride=(2, 1, 1))
-    assert rel_l2(got, ref.permute(0, 2, 3, 4, 1)) < 3e-3
+    assert rel_l2(got, ref.permute(0, 2, 3, 4, 1), bound=3e-3) < 3e-3
 
 
 @pytest.mark.parametrize("k", [0, 2])
