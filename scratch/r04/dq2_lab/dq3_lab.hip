@@ -1,3 +1,4 @@
+// LAB: pass B with 32-key half tiles (generated once from attn_bwd_dq2.hip, then edited)
 // Attention backward, pass B (dQ), second form - for the self-attention path where q is pre-scaled into log2 units
 // (scale * log2(e) == 1; attn_fwd.hip, VAR bit 1).  Same geometry as attn_bwd_dq_kernel (8 waves x 32 query rows, 64-key tiles,
 // query on the lane, S^T = K Q^T, dP^T = V dO^T, dQ^T += K^T dS^T), rebuilt like the forward kernel:
@@ -6,15 +7,16 @@
 //   * row constants as the initial accumulator (cdna_hip_programming.md, attention backward): the score accumulators START at
 //     -lse (log2 units), so P = exp2(accumulator) needs no multiply-subtract, and the softmax scale is applied once to dQ in the
 //     epilogue instead of to every dS:  dS' = P * (dP - delta)  is 2 vector instructions per score instead of 5.
-//   * (round 4) a 64-key tile is worked through as two 32-key halves - S / dP of a half (16 MFMAs), its dS', its 8 dQ MFMAs - so
-//     the score accumulators take 32 registers instead of 64, and the 32 freed hold fragment reads two MFMA pairs ahead.  At 256
-//     registers hipcc had put 29 of the 64 fragment reads of a tile directly in front of their MFMA behind `lgkmcnt(0)`
-//     (SQ_WAIT_ANY 0.41 of the wave cycles -> 0.15 now).  Bit-identical (same products, same order per accumulator); +3 % only:
-//     with the waits gone the chip lowers its clock (1.74 -> 1.65 GHz at MFMA busy 0.64 -> 0.70): profiles/r04_attn_bwd_passB.md.
 // This loop, like the forward, is vector-issue bound: the file is built without SLP vectorisation (lcv_hip/build.py).
 #include "lcv_common.h"
 #include <stdlib.h>
 #include <type_traits>
+#ifndef DQ3_DEPTH
+#define DQ3_DEPTH 2
+#endif
+#ifndef DQ3_TRD
+#define DQ3_TRD 2
+#endif
 
 typedef __attribute__((address_space(3))) unsigned char lds_u8;
 typedef __attribute__((address_space(1))) void gbl_void_q;
@@ -46,7 +48,6 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   constexpr int QROWS = NW * 32;
   constexpr int NP = 16 / NW;                  // one-KiB DMA pieces per wave, tile and tensor (4 rows each)
   constexpr int TILE_BYTES = 64 * 256;
-  constexpr int ROW_AHEAD = 2, TR_AHEAD = 2;   // fragment reads in flight ahead of their MFMAs: K / V row fragments (pairs), K^T fragments
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   lds_u8* lds = (lds_u8*)smem;  // [NS][K tile | V tile]
 
@@ -174,9 +175,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const lds_u8* kb = lds + buf * 2 * TILE_BYTES;
     const lds_u8* vb = kb + TILE_BYTES;
 
-    // two 32-key halves, one after the other (see the head of the file); dS' = P * (dP - delta), P = exp2(S - lse): the scale is
-    // applied to dQ once, in the epilogue.  (Starting the dP accumulators at -delta, as the scores start at -lse, saves the 32
-    // subtractions but needs a second resident 16-register tuple: not kept, round 3.)
+    // two 32-key halves, one after the other: 32 accumulator registers for S / dP instead of 64, and what that frees holds K / V
+    // fragments TWO steps ahead of the MFMAs that use them (at 256 registers hipcc issued every fragment read directly in front
+    // of its MFMA: 29 full LDS latencies per tile on the issue path)
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       const lds_u8* kh = kb + half * 32 * 256 + k_row_off;
@@ -185,20 +186,24 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
       f32x16 s, d;
 #pragma unroll
       for (int e = 0; e < 16; ++e) { s[e] = sinit; d[e] = 0.f; }
-      bf16x8 af[ROW_AHEAD + 1], cf[ROW_AHEAD + 1];
+      bf16x8 af[DQ3_DEPTH + 1], cf[DQ3_DEPTH + 1];
 #pragma unroll
-      for (int i = 0; i < ROW_AHEAD; ++i) {
+      for (int i = 0; i < DQ3_DEPTH; ++i) {
         af[i] = *reinterpret_cast<const AS3 bf16x8*>(kh + co(i));
         cf[i] = *reinterpret_cast<const AS3 bf16x8*>(vh + co(i));
       }
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
-        if (ks + ROW_AHEAD < 8) {
-          af[(ks + ROW_AHEAD) % (ROW_AHEAD + 1)] = *reinterpret_cast<const AS3 bf16x8*>(kh + co(ks + ROW_AHEAD));
-          cf[(ks + ROW_AHEAD) % (ROW_AHEAD + 1)] = *reinterpret_cast<const AS3 bf16x8*>(vh + co(ks + ROW_AHEAD));
+        if (ks + DQ3_DEPTH < 8) {
+          af[(ks + DQ3_DEPTH) % (DQ3_DEPTH + 1)] = *reinterpret_cast<const AS3 bf16x8*>(kh + co(ks + DQ3_DEPTH));
+          cf[(ks + DQ3_DEPTH) % (DQ3_DEPTH + 1)] = *reinterpret_cast<const AS3 bf16x8*>(vh + co(ks + DQ3_DEPTH));
         }
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks % (ROW_AHEAD + 1)], qf[ks], s, 0, 0, 0);
-        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cf[ks % (ROW_AHEAD + 1)], dof[ks], d, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks % (DQ3_DEPTH + 1)], qf[ks], s, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cf[ks % (DQ3_DEPTH + 1)], dof[ks], d, 0, 0, 0);
+#ifdef DQ3_SGB
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // 2 DS reads
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // 2 MFMA
+#endif
       }
       if (!has_next && (p.Nk & 63)) {  // last tile only
         const int valid = (int)(p.Nk - (int64_t)t * 64) - 32 * half;
@@ -208,7 +213,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
           if (key >= valid) s[e] = -INFINITY;
         }
       }
-      // K^T fragments of this half's 8 dQ products (i = 2 kk2 + ... : kk2 = i >> 2, dd = i & 3), TR_AHEAD products ahead; the
+      // K^T fragments of this half's 8 dQ products (i = 2 kk2 + ... : kk2 = i >> 2, dd = i & 3), DQ3_TRD products ahead; the
       // first ones are requested BEFORE the vector work on the scores, which hides their latency
       auto ktf_read = [&](int i) {
         const int kk = 2 * half + (i >> 2), dd = i & 3;
@@ -217,9 +222,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((AS3 s16x4*)(kb + t_base[1] + 4096 * kk + dx + 16 * t_low[1]));
         return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
       };
-      bf16x8 ktf[TR_AHEAD + 1];
+      bf16x8 ktf[DQ3_TRD + 1];
 #pragma unroll
-      for (int i = 0; i < TR_AHEAD; ++i) ktf[i] = ktf_read(i);
+      for (int i = 0; i < DQ3_TRD; ++i) ktf[i] = ktf_read(i);
 #pragma unroll
       for (int e = 0; e < 16; ++e) s[e] = __builtin_amdgcn_exp2f(s[e]) * (d[e] - delta_q);
       bf16x8 dsb[2];
@@ -230,8 +235,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
       }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        if (i + TR_AHEAD < 8) ktf[(i + TR_AHEAD) % (TR_AHEAD + 1)] = ktf_read(i + TR_AHEAD);
-        dqacc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[i % (TR_AHEAD + 1)], dsb[i >> 2], dqacc[i & 3], 0, 0, 0);
+        if (i + DQ3_TRD < 8) ktf[(i + DQ3_TRD) % (DQ3_TRD + 1)] = ktf_read(i + DQ3_TRD);
+        dqacc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[i % (DQ3_TRD + 1)], dsb[i >> 2], dqacc[i & 3], 0, 0, 0);
       }
     }
     if (has_next) {   // tile t+1 is in; what was requested after it may still be in flight
