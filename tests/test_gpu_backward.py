@@ -41,9 +41,9 @@ def test_attention_backward(B, H, Nq, Nk):
     s = (qf @ kf.transpose(-1, -2)) * scale
     ref = torch.softmax(s, -1) @ vf
     ref.backward(do.float().permute(0, 2, 1, 3))
-    assert rel_l2(dq.permute(0, 2, 1, 3), qf.grad, bound=1e-2) < 1e-2
-    assert rel_l2(dk.permute(0, 2, 1, 3), kf.grad, bound=1e-2) < 1e-2
-    assert rel_l2(dv.permute(0, 2, 1, 3), vf.grad, bound=1e-2) < 1e-2
+    assert rel_l2(dq.permute(0, 2, 1, 3), qf.grad, bound=4.0e-3) < 4.0e-3
+    assert rel_l2(dk.permute(0, 2, 1, 3), kf.grad, bound=3.8e-3) < 3.8e-3
+    assert rel_l2(dv.permute(0, 2, 1, 3), vf.grad, bound=3.6e-3) < 3.6e-3
     # no atomics on any path (the split query sweep of the short-key form keeps a slice per split): a second call gives the same bits
     dq_b = torch.empty_like(qd); dk_b = torch.empty_like(kd); dv_b = torch.empty_like(vd)
     ops.attention_bwd(qd, kd, vd, o, dod, lse, dq_b, dk_b, dv_b, scale)
@@ -97,9 +97,9 @@ def test_attention_backward_unit_scale_forms_on_the_product_layout(B, H, Nq, Nk,
     ref = torch.softmax((qf @ kf.transpose(-1, -2)) * math.log(2.0), -1) @ vf
     ref.backward(do.float().permute(0, 2, 1, 3))
     dq, dk, dv = outs["4"]
-    assert rel_l2(dq.permute(0, 2, 1, 3), qf.grad, bound=1e-2) < 1e-2
-    assert rel_l2(dk.permute(0, 2, 1, 3), kf.grad, bound=1e-2) < 1e-2
-    assert rel_l2(dv.permute(0, 2, 1, 3), vf.grad, bound=1e-2) < 1e-2
+    assert rel_l2(dq.permute(0, 2, 1, 3), qf.grad, bound=4.0e-3) < 4.0e-3
+    assert rel_l2(dk.permute(0, 2, 1, 3), kf.grad, bound=4.2e-3) < 4.2e-3
+    assert rel_l2(dv.permute(0, 2, 1, 3), vf.grad, bound=3.6e-3) < 3.6e-3
 
 
 def test_norm_gate_swiglu_backward():
@@ -113,26 +113,26 @@ def test_norm_gate_swiglu_backward():
     xf = x.float().requires_grad_(True); mf = mod.clone().requires_grad_(True)
     y = orc.modulate_fp32(xf.view(B, T, S, C), mf[..., :C].unsqueeze(2), mf[..., C:2 * C].unsqueeze(2))
     y.backward(dy.float().view(B, T, S, C))
-    assert rel_l2(dx, xf.grad, bound=5e-3) < 5e-3 and rel_l2(dmod, mf.grad, bound=1e-4) < 1e-4
+    assert rel_l2(dx, xf.grad, bound=2.5e-3) < 2.5e-3 and rel_l2(dmod, mf.grad, bound=1.0e-6) < 1.0e-6
     # affine LayerNorm with parameter grads
     w = _randn(C, seed=8); b = _randn(C, seed=9)
     dx, dw, db = ops.layernorm_affine_bwd(x.to(DEV), w.to(DEV), dy.to(DEV), need_dw=True)
     xf = x.float().requires_grad_(True); wf = w.float().requires_grad_(True); bf = b.float().requires_grad_(True)
     orc.layernorm_fp32(xf, wf, bf).backward(dy.float())
-    assert rel_l2(dx, xf.grad, bound=5e-3) < 5e-3 and rel_l2(dw, wf.grad, bound=1e-4) < 1e-4 and rel_l2(db, bf.grad, bound=1e-4) < 1e-4
+    assert rel_l2(dx, xf.grad, bound=2.5e-3) < 2.5e-3 and rel_l2(dw, wf.grad, bound=1.0e-6) < 1.0e-6 and rel_l2(db, bf.grad, bound=1.0e-6) < 1.0e-6
     # gated residual
     yv = _randn(B, T * S, C, seed=10)
     dyy, dmod = ops.gate_residual_bwd(yv.to(DEV), mod.to(DEV), dy.to(DEV), 2, T, need_dmod=True)
     g = mod[..., 2 * C:3 * C].unsqueeze(2)
-    assert rel_l2(dyy, (g * dy.float().view(B, T, S, C)).view(B, T * S, C), bound=5e-3) < 5e-3
+    assert rel_l2(dyy, (g * dy.float().view(B, T, S, C)).view(B, T * S, C), bound=2.5e-3) < 2.5e-3
     ref_dg = (dy.float() * yv.float()).view(B, T, S, C).sum(2)
-    assert rel_l2(dmod[..., 2 * C:3 * C], ref_dg, bound=1e-4) < 1e-4 and dmod[..., :2 * C].abs().max().item() == 0
+    assert rel_l2(dmod[..., 2 * C:3 * C], ref_dg, bound=1.0e-6) < 1.0e-6 and dmod[..., :2 * C].abs().max().item() == 0
     # swiglu
     gte = _randn(40, 256, seed=11); up = _randn(40, 256, seed=12); dout = _randn(40, 256, seed=13)
     dg, du = ops.swiglu_bwd(gte.to(DEV), up.to(DEV), dout.to(DEV))
     gf = gte.float().requires_grad_(True); uf = up.float().requires_grad_(True)
     (F.silu(gf) * uf).backward(dout.float())
-    assert rel_l2(dg, gf.grad, bound=5e-3) < 5e-3 and rel_l2(du, uf.grad, bound=5e-3) < 5e-3
+    assert rel_l2(dg, gf.grad, bound=3.7e-3) < 3.7e-3 and rel_l2(du, uf.grad, bound=3.7e-3) < 3.7e-3
 
 
 def test_fused_swiglu_training_path_matches_the_unfused_form():
@@ -193,13 +193,13 @@ def test_qknorm_rope_backward():
         src = qkv[:, :, idx].float().permute(0, 2, 1, 3).requires_grad_(True)
         out = orc.apply_rope(orc.rmsnorm_fp32(src, w), ang)
         out.backward(dout.float().permute(0, 2, 1, 3))
-        assert rel_l2(got.permute(0, 2, 1, 3), src.grad, bound=5e-3) < 5e-3, idx
+        assert rel_l2(got.permute(0, 2, 1, 3), src.grad, bound=2.5e-3) < 2.5e-3, idx
     # q_scale: the forward multiplied q by c, so dq_in scales by c; dk_in does not
     c = ops.log2_qscale(D ** -0.5)
     dqi2 = torch.empty_like(dqi); dki2 = torch.empty_like(dqi)
     ops.qknorm_rope_bwd(d[:, :, 0], d[:, :, 1], dq.to(DEV), dk.to(DEV), dqi2, dki2, wq.to(DEV), wk.to(DEV), cs.to(DEV),
                         q_scale=c)
-    assert rel_l2(dqi2, dqi.float() * c, bound=5e-3) < 5e-3 and torch.equal(dki2, dki)
+    assert rel_l2(dqi2, dqi.float() * c, bound=3.5e-3) < 3.5e-3 and torch.equal(dki2, dki)
 
 
 def test_linear_f32_backward_and_tn_skinny_and_unpatchify():
@@ -210,12 +210,12 @@ def test_linear_f32_backward_and_tn_skinny_and_unpatchify():
     da = ops.linear_f32_smallm_bwd(dy.to(DEV), w.to(DEV), a.to(DEV), act_in=1)
     af = a.clone().requires_grad_(True)
     (F.silu(af) @ w.float().t()).backward(dy)
-    assert rel_l2(da, af.grad, bound=1e-4) < 1e-4
+    assert rel_l2(da, af.grad, bound=1.0e-6) < 1.0e-6
     g = _randn(300, 64, seed=22); x = _randn(300, 4096, seed=23)
     out = ops.tn_skinny(g.to(DEV), x.to(DEV), 8, scale=2.0)
-    assert rel_l2(out, 2.0 * g[:, :8].float().t() @ x.float(), bound=1e-4) < 1e-4
+    assert rel_l2(out, 2.0 * g[:, :8].float().t() @ x.float(), bound=1.0e-6) < 1.0e-6
     out = ops.tn_skinny(g.to(DEV), x.to(DEV), 20, scale=1.0)
-    assert rel_l2(out, g[:, :20].float().t() @ x.float(), bound=1e-4) < 1e-4
+    assert rel_l2(out, g[:, :20].float().t() @ x.float(), bound=1.0e-6) < 1.0e-6
     dout = _randn(2, 16, 3, 8, 12, seed=24, dtype=torch.float32)
     dtok = ops.unpatchify_bwd(dout.to(DEV), 16, 3, 8, 12)
     from oracle import dit_oracle as orc
@@ -242,8 +242,8 @@ def test_lora_linear_matches_reference_fixture():
     y.backward(t["gy"].to(DEV))
     assert abs(lora.scaling - float(t["scaling"])) < 1e-12
     # the reference rounds after every bf16 op; the fused path accumulates in fp32 -> compare within bf16 noise
-    assert rel_l2(y, t["y"].float(), bound=6e-3) < 6e-3
-    assert rel_l2(x.grad, t["dx"].float(), bound=1e-2) < 1e-2
+    assert rel_l2(y, t["y"].float(), bound=4.4e-3) < 4.4e-3
+    assert rel_l2(x.grad, t["dx"].float(), bound=4.3e-3) < 4.3e-3
     assert rel_l2(lora.lora_down.weight.grad, t["dA"].float(), bound=1e-2) < 1e-2
     assert rel_l2(lora.lora_up.weight.grad, t["dB"].float(), bound=1e-2) < 1e-2
 
@@ -719,7 +719,7 @@ def test_builtin_lora_module_path_forward_and_gradients_match_oracle():
     ref = orc.dit_forward(P2, cfg, hs, ts.to(BF16), y, mask, 1, bf16=False)
     ref_loss = torch.nn.functional.mse_loss(ref[:, :, 1:], (eps - x0).float())
     ref_loss.backward()
-    assert rel_l2(pred, ref, bound=1e-2) < 1e-2 and abs(loss.item() - ref_loss.item()) < 2e-2 * ref_loss.item()
+    assert rel_l2(pred, ref, bound=6.8e-3) < 6.8e-3 and abs(loss.item() - ref_loss.item()) < 2e-2 * ref_loss.item()
     got = get_builtin_lora_parameters(mods)
     assert len(got) == len(leaves)
     errs = [rel_l2(p.grad, l.grad) for p, l in zip(got, leaves)]

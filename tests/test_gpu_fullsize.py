@@ -48,7 +48,7 @@ def test_attention_k3_rows_vs_fp32_and_properties():
     for h in (0, 7, 19, 31):
         s = (q[0, rows, h].float() @ k[0, :, h].float().t()) * scale
         ref = torch.softmax(s, dim=-1) @ v[0, :, h].float()
-        assert rel_l2(o[0, rows, h], ref, bound=6e-3) < 6e-3, h
+        assert rel_l2(o[0, rows, h], ref, bound=3.6e-3) < 3.6e-3, h
         assert torch.allclose(lse[0, h, rows], torch.logsumexp(s, dim=-1), atol=3e-4, rtol=1e-5)
     # (ii-a) rows of P sum to one: V = 1 gives O = 1 up to the bf16 rounding of P and O
     ones = torch.ones_like(v)
@@ -66,7 +66,7 @@ def test_attention_k3_rows_vs_fp32_and_properties():
     v2 = torch.randn((1, N_K3, H, D), generator=g, device=DEV).to(BF16)
     ob, _ = ops.attention(q, k, v2, scale)
     oc, _ = ops.attention(q, k, (v.float() + 2.0 * v2.float()).to(BF16), scale)
-    assert rel_l2(oc, o.float() + 2.0 * ob.float(), bound=8e-3) < 8e-3
+    assert rel_l2(oc, o.float() + 2.0 * ob.float(), bound=4.5e-3) < 4.5e-3
 
 
 @pytest.mark.parametrize("name,N,K", [("qkv", 3 * C, C), ("proj", C, C), ("w2", C, F_)])
@@ -86,7 +86,7 @@ def test_gemm_k3_rows_vs_fp32_and_linearity(name, N, K):
     c12 = ops.gemm_nt((a.float() + a2.float()).to(BF16), w, b)
     # bf16(a + a2) is itself rounded: compare against the exact fp32 product on the sampled rows, and linearity loosely
     assert rel_l2(c12[rows], (a[rows].float() + a2[rows].float()).to(BF16).float() @ w.float().t() + b.float(), bound=2e-3) < 2e-3
-    assert rel_l2(c12, c.float() + c2.float(), bound=1.5e-2) < 1.5e-2
+    assert rel_l2(c12, c.float() + c2.float(), bound=4.3e-3) < 4.3e-3
 
 
 def test_swiglu_gemm_k3_rows_vs_fp32():
@@ -174,12 +174,12 @@ def test_attention_backward_k3_tta_rows_vs_fp32():
         # key subset: all queries x 40 keys
         p_ = torch.exp(qf @ kf[ks].t() * scale - lse[0, h][:, None])  # [N, 40]
         ds = p_ * (dof @ vf[ks].t() - delta[:, None])
-        assert rel_l2(dqkv[0, ks, 2, h], p_.t() @ dof, bound=8e-3) < 8e-3, ("dV", h)
-        assert rel_l2(dqkv[0, ks, 1, h], scale * ds.t() @ qf, bound=8e-3) < 8e-3, ("dK", h)
+        assert rel_l2(dqkv[0, ks, 2, h], p_.t() @ dof, bound=3.6e-3) < 3.6e-3, ("dV", h)
+        assert rel_l2(dqkv[0, ks, 1, h], scale * ds.t() @ qf, bound=3.7e-3) < 3.7e-3, ("dK", h)
         # query subset: 40 queries x all keys
         p2 = torch.exp(qf[rs] @ kf.t() * scale - lse[0, h][rs][:, None])  # [40, N]
         ds2 = p2 * (dof[rs] @ vf.t() - delta[rs][:, None])
-        assert rel_l2(dqkv[0, rs, 0, h], scale * ds2 @ kf, bound=8e-3) < 8e-3, ("dQ", h)
+        assert rel_l2(dqkv[0, rs, 0, h], scale * ds2 @ kf, bound=3.6e-3) < 3.6e-3, ("dQ", h)
 
 
 def test_fused_adamw_clip_full_lora_parameter_set_vs_torch():
@@ -291,7 +291,7 @@ def test_attention_k3p_176400_tokens_rows_vs_fp32_and_key_permutation():
     for h in (0, 11, 31):
         s = (q[0, rows, h].float() @ k[0, :, h].float().t()) * ops.LN2
         ref = torch.softmax(s, dim=-1) @ v[0, :, h].float()
-        assert rel_l2(o[0, rows, h], ref, bound=6e-3) < 6e-3, h
+        assert rel_l2(o[0, rows, h], ref, bound=3.6e-3) < 3.6e-3, h
         assert torch.allclose(lse[0, h, rows], torch.logsumexp(s, dim=-1), atol=3e-4, rtol=1e-5)
     perm = torch.randperm(N_K3P, generator=g, device=DEV)
     o2, _ = ops.attention(q, k[:, perm].contiguous(), v[:, perm].contiguous(), ops.LN2)

@@ -105,7 +105,7 @@ def test_row_tile_conv_kernel(ci, co, k, up, W, resid, monkeypatch):
     if resid:
         ref = r[..., :co].float() + ref.to(BF16).float()
     assert rel_l2(got, ref, bound=3e-3) < 3e-3
-    assert rel_l2(got, old, bound=3e-3) < 3e-3 and not torch.equal(got, torch.zeros_like(got))
+    assert rel_l2(got, old, bound=5.5e-5) < 5.5e-5 and not torch.equal(got, torch.zeros_like(got))
 
 
 @pytest.mark.parametrize("T", [1, 3])
