@@ -213,9 +213,27 @@ def generate_continuation(pipe, blob, args, idx, device, num_frames=None, entry=
     return out, time.time() - t0
 
 
-def save_frames(pipe, latents, path_noext: str, frames: torch.Tensor = None):
+_VIDEO_WRITER_NOTE = [False]
+
+
+def save_frames(pipe, latents, path_noext: str, frames: torch.Tensor = None, fps: int = 24):
+    """The generated clip as `<name>.mp4` exactly as the reference writes it (`save_video_from_numpy`, run_lora_tta.py:641-647:
+    `imageio.mimwrite(path, uint8 frames, fps=24, codec="libx264", quality=9)`) when `imageio` (+ its ffmpeg plugin) is importable;
+    in an image without it (this one: no video encoder of any kind) the same uint8 frame stack goes to `<name>.npy` and one line
+    says so.  Host-side file output only: nothing of the compute path depends on which of the two was written."""
     frames = pipe.decode_to_frames(latents) if frames is None else frames
-    np.save(path_noext + ".npy", (frames * 255).to(torch.uint8).cpu().numpy())
+    frames_u8 = (frames * 255).to(torch.uint8).cpu().numpy()
+    try:
+        import imageio
+    except ImportError:
+        imageio = None
+    if imageio is not None:
+        imageio.mimwrite(path_noext + ".mp4", frames_u8, fps=fps, codec="libx264", quality=9)
+        return path_noext + ".mp4"
+    if not _VIDEO_WRITER_NOTE[0]:
+        _VIDEO_WRITER_NOTE[0] = True
+        print("  (imageio is not installed: generated clips are saved as uint8 .npy frame stacks instead of .mp4)")
+    np.save(path_noext + ".npy", frames_u8)
     return path_noext + ".npy"
 
 

@@ -109,3 +109,27 @@ def test_loss_curves_are_extractable(run):
         assert steps == sorted(steps) and steps[0] == 0 and all(isinstance(p[1], float) and math.isfinite(p[1]) for p in lh)
     assert statistics.mean([r["psnr"] for r in ok if r.get("psnr") and not math.isnan(r["psnr"])]) > 0
     assert (s.get("delta_steps") or s.get("num_steps") or 0) >= 0
+
+
+def test_generated_clip_goes_through_imageio_like_the_reference_when_it_is_installed(tmp_path, monkeypatch):
+    """`save_frames` mirrors `save_video_from_numpy` (run_lora_tta.py:641-647): uint8 frames, fps 24, libx264, quality 9, `.mp4`;
+    without imageio (this image) the same frames land in a `.npy` stack."""
+    import sys
+    import types
+    import numpy as np
+    import torch
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "longcat-video-tta_amd"))
+    from tta import runner_common as R
+    frames = torch.rand(3, 8, 8, 3)
+    monkeypatch.setitem(sys.modules, "imageio", None)          # import imageio -> ImportError
+    out = R.save_frames(None, None, str(tmp_path / "clip_lora"), frames=frames)
+    assert out.endswith("clip_lora.npy")
+    got = np.load(out)
+    assert got.dtype == np.uint8 and got.shape == (3, 8, 8, 3) and np.array_equal(got, (frames * 255).to(torch.uint8).numpy())
+    calls = []
+    fake = types.ModuleType("imageio")
+    fake.mimwrite = lambda path, fr, **kw: calls.append((path, fr.dtype, fr.shape, kw))
+    monkeypatch.setitem(sys.modules, "imageio", fake)
+    out = R.save_frames(None, None, str(tmp_path / "clip_lora"), frames=frames)
+    assert out.endswith("clip_lora.mp4")
+    assert calls == [(out, np.dtype("uint8"), (3, 8, 8, 3), {"fps": 24, "codec": "libx264", "quality": 9})]
