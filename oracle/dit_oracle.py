@@ -131,6 +131,65 @@ def sdpa(q, k, v, scale, rnd=_id):
     return outs[0] if len(outs) == 1 else torch.cat(outs, dim=1)
 
 
+def sdpa_at_kernel_rounding(q, k, v, scale, tile=64, group=32, thr=6.0, row0=0):
+    """The forward attention kernels' arithmetic restated tile by tile (checker for tests/test_gpu_kernels.py and
+    test_gpu_fullsize.py, not a second definition of the op; csrc/attn_fwd.hip:284-345, attn_fwd_pipe.hip, attn_fwd_w64.hip:233-256):
+    keys in tiles of 64; scores in log2 units; the running max of a query row is raised only when SOME row of its 32-row group sees a
+    tile maximum more than 2^6 above its own running max (and on the first tile), then O and l are rescaled; P = exp2(s - m_run) is
+    rounded to bf16 as the MFMA operand of P V while the row sum takes the unrounded fp32 P; O / l is stored in bf16.
+    `row0`: index of q's first row inside the launch (groups are aligned to the launch's row 0), for checks on a slice of rows.
+    Against this the kernels differ only by fp32 summation order and the bf16 flips that follow from it."""
+    c = scale * 1.4426950408889634
+    B, H, Nq, D = q.shape
+    Nk = k.shape[2]
+    qf, kf, vf = q.float(), k.float(), v.float()
+    gid = (torch.arange(Nq) + row0) // group
+    gid = gid - gid.min()
+    ng = int(gid.max()) + 1
+    m = torch.zeros(B, H, Nq)
+    l = torch.zeros(B, H, Nq)
+    o = torch.zeros(B, H, Nq, D)
+    for t, k0 in enumerate(range(0, Nk, tile)):
+        s = (qf @ kf[:, :, k0:k0 + tile].transpose(-1, -2)) * c
+        mx = s.amax(dim=-1)
+        if t == 0:
+            m_new = mx
+        else:
+            grew = ((mx - m) > thr).float()
+            over = torch.zeros(B, H, ng).scatter_reduce_(2, gid.expand(B, H, Nq), grew, "amax", include_self=True) > 0
+            m_new = torch.where(over[:, :, gid], torch.maximum(m, mx), m)
+        alpha = torch.exp2(m - m_new) if t else torch.zeros_like(m)
+        m = m_new
+        pt = torch.exp2(s - m.unsqueeze(-1))
+        l = l * alpha + pt.sum(dim=-1)
+        o = o * alpha.unsqueeze(-1) + bf16_round(pt) @ vf[:, :, k0:k0 + tile]
+    return bf16_round(o / l.unsqueeze(-1))
+
+
+def sdpa_backward_at_kernel_rounding(q, k, v, d_o, scale, scale_inside=True, o=None, lse=None):
+    """dq, dk, dv of softmax(q k^T scale) v at the backward kernels' rounding points: P and dS are bf16 MFMA operands, results
+    stored in bf16.  `o` [B,H,Nq,D] and `lse` [B,H,Nq] (natural log): the forward's outputs, which the kernels take as INPUTS
+    (delta = rowsum(dO * O), P = exp(s - lse)); without them the fp32 softmax and its bf16-rounded output stand in.
+    `scale_inside`: the general-scale forms round dS = P (dP - delta) * scale (csrc/attn_bwd.hip:214-223, 451-454); the unit-scale
+    forms the DiT's self-attention takes (q already in log2 units, scale = ln 2) round dS' = P (dP - delta) and multiply dQ / dK by
+    the scale afterwards (attn_bwd_dq2.hip, attn_bwd_dkv2.hip) - with a scale that is not a power of two those are different
+    roundings."""
+    qf, kf, vf, gf = q.float(), k.float(), v.float(), d_o.float()
+    s = (qf @ kf.transpose(-1, -2)) * scale
+    p = torch.softmax(s, dim=-1) if lse is None else torch.exp(s - lse.float().unsqueeze(-1))
+    of = bf16_round(p @ vf) if o is None else o.float()
+    delta = (gf * of).sum(dim=-1, keepdim=True)
+    dv = bf16_round(p).transpose(-1, -2) @ gf
+    dp = gf @ vf.transpose(-1, -2)
+    if scale_inside:
+        ds = bf16_round(p * (dp - delta) * scale)
+        dq, dk = ds @ kf, ds.transpose(-1, -2) @ qf
+    else:
+        ds = bf16_round(p * (dp - delta))
+        dq, dk = (ds @ kf) * scale, (ds.transpose(-1, -2) @ qf) * scale
+    return bf16_round(dq), bf16_round(dk), bf16_round(dv)
+
+
 # --------------------------------------------------------------------------- block pieces
 def self_attention(P: Dict[str, torch.Tensor], pre: str, x, shape, num_cond_latents, num_heads, rnd=_id,
                    kv_cache=None, return_kv=False):

@@ -7,6 +7,7 @@ P/dS are rounded to bf16 before their MFMAs exactly like the forward); optimizer
 fraction of 1-ulp flips caused by the norm's summation order.
 """
 import json
+import sys
 from pathlib import Path
 
 import pytest
@@ -44,6 +45,14 @@ def test_attention_backward(B, H, Nq, Nk):
     assert rel_l2(dq.permute(0, 2, 1, 3), qf.grad, bound=4.0e-3) < 4.0e-3
     assert rel_l2(dk.permute(0, 2, 1, 3), kf.grad, bound=3.8e-3) < 3.8e-3
     assert rel_l2(dv.permute(0, 2, 1, 3), vf.grad, bound=3.6e-3) < 3.6e-3
+    # ... and against the checker that rounds where the kernels round (P and dS as bf16 MFMA operands, bf16 results)
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+    from oracle import dit_oracle as orc
+    rq, rk, rv = orc.sdpa_backward_at_kernel_rounding(*(t.permute(0, 2, 1, 3) for t in (q, k, v, do)), scale, scale_inside=True,
+                                                      o=o.cpu().permute(0, 2, 1, 3), lse=lse.cpu())
+    assert rel_l2(dq.permute(0, 2, 1, 3), rq, bound=1.6e-4) < 1.6e-4
+    assert rel_l2(dk.permute(0, 2, 1, 3), rk, bound=2.7e-4) < 2.7e-4
+    assert rel_l2(dv.permute(0, 2, 1, 3), rv, bound=2.0e-4) < 2.0e-4
     # no atomics on any path (the split query sweep of the short-key form keeps a slice per split): a second call gives the same bits
     dq_b = torch.empty_like(qd); dk_b = torch.empty_like(kd); dv_b = torch.empty_like(vd)
     ops.attention_bwd(qd, kd, vd, o, dod, lse, dq_b, dk_b, dv_b, scale)
@@ -100,6 +109,15 @@ def test_attention_backward_unit_scale_forms_on_the_product_layout(B, H, Nq, Nk,
     assert rel_l2(dq.permute(0, 2, 1, 3), qf.grad, bound=4.0e-3) < 4.0e-3
     assert rel_l2(dk.permute(0, 2, 1, 3), kf.grad, bound=4.2e-3) < 4.2e-3
     assert rel_l2(dv.permute(0, 2, 1, 3), vf.grad, bound=3.6e-3) < 3.6e-3
+    # ... and the checker at these forms' rounding points (dS' = P (dP - delta) rounded BEFORE the scale)
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+    from oracle import dit_oracle as orc
+    rq, rk, rv = orc.sdpa_backward_at_kernel_rounding(qk[:, :Nq, 0].permute(0, 2, 1, 3), qk[:, :Nk, 1].permute(0, 2, 1, 3),
+                                                      qkv[:, :, 2].permute(0, 2, 1, 3), do.permute(0, 2, 1, 3), math.log(2.0),
+                                                      scale_inside=False, o=o.cpu().permute(0, 2, 1, 3), lse=lse.cpu())
+    assert rel_l2(dq.permute(0, 2, 1, 3), rq, bound=2.6e-4) < 2.6e-4
+    assert rel_l2(dk.permute(0, 2, 1, 3), rk, bound=3.0e-4) < 3.0e-4
+    assert rel_l2(dv.permute(0, 2, 1, 3), rv, bound=3.0e-4) < 3.0e-4
 
 
 def test_norm_gate_swiglu_backward():

@@ -50,6 +50,18 @@ def test_attention_k3_rows_vs_fp32_and_properties():
         ref = torch.softmax(s, dim=-1) @ v[0, :, h].float()
         assert rel_l2(o[0, rows, h], ref, bound=3.6e-3) < 3.6e-3, h
         assert torch.allclose(lse[0, h, rows], torch.logsumexp(s, dim=-1), atol=3e-4, rtol=1e-5)
+    # (i-b) whole 32-row groups (the first, one inside, the ragged last one: 46 800 = 1 462 x 32 + 16) against the tile-by-tile
+    # restatement of the kernel's own arithmetic (oracle/dit_oracle.py::sdpa_at_kernel_rounding: deferred running max per group, P
+    # rounded to bf16 against it) over all 732 key tiles: what is left is fp32 summation order
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+    from oracle import dit_oracle as orc
+    for r0, r1 in ((0, 32), (23456, 23488), (N_K3 - 16, N_K3)):
+        for h in (0, 31):
+            ref_r = orc.sdpa_at_kernel_rounding(q[:, r0:r1, h].cpu()[:, None], k[:, :, h].cpu()[:, None], v[:, :, h].cpu()[:, None], scale,
+                                                row0=r0)
+            assert rel_l2(o[0, r0:r1, h], ref_r[0, 0], bound=4.6e-4) < 4.6e-4, (r0, h)
     # (ii-a) rows of P sum to one: V = 1 gives O = 1 up to the bf16 rounding of P and O
     ones = torch.ones_like(v)
     o1, _ = ops.attention(q, k, ones, scale)
@@ -180,6 +192,12 @@ def test_attention_backward_k3_tta_rows_vs_fp32():
         p2 = torch.exp(qf[rs] @ kf.t() * scale - lse[0, h][rs][:, None])  # [40, N]
         ds2 = p2 * (dof[rs] @ vf.t() - delta[rs][:, None])
         assert rel_l2(dqkv[0, rs, 0, h], scale * ds2 @ kf, bound=3.6e-3) < 3.6e-3, ("dQ", h)
+        # the same formulas at the kernels' rounding points (general-scale forms: P and dS * scale are bf16 MFMA operands, bf16
+        # results; csrc/attn_bwd.hip:214-223, 451-454): what is left is fp32 summation order
+        rb = lambda t: t.to(BF16).float()
+        assert rel_l2(dqkv[0, ks, 2, h], rb(rb(p_).t() @ dof), bound=6.4e-4) < 6.4e-4, ("dV at the kernel's rounding", h)
+        assert rel_l2(dqkv[0, ks, 1, h], rb(rb(ds * scale).t() @ qf), bound=5.0e-4) < 5.0e-4, ("dK at the kernel's rounding", h)
+        assert rel_l2(dqkv[0, rs, 0, h], rb(rb(ds2 * scale) @ kf), bound=4.1e-4) < 4.1e-4, ("dQ at the kernel's rounding", h)
 
 
 def test_fused_adamw_clip_full_lora_parameter_set_vs_torch():
