@@ -359,6 +359,47 @@ def test_gemm4k_default_kernel_bitwise_every_epilogue(M, N, K, K2, kind, monkeyp
                 assert torch.equal(kw["swiglu_aux"], aux_ref)
 
 
+def test_gemm_dispatch_fuzz_bitwise_against_the_one_barrier_kernel(monkeypatch):
+    """40 seeded random calls through the dispatcher (which picks gemm4k wherever its epilogue serves the call and the round-3 kernels
+    elsewhere) against the one-barrier kernel, bit for bit: row counts from 1 to 3 000 incl. +-1 around tile multiples, every N
+    multiple of 256 up to 1 280 plus one that is not, K from 128, with / without the rank-r K tiles, bias, the gate-residual epilogue
+    with frame lengths above and below the 128 rows gemm4k needs, SwiGLU.  (The one GPU fault of round 4 was an edge of exactly this
+    kind: a wave tile wholly past M looking up its frame's gate row.)"""
+    ops = _ops()
+    from lcv_hip.lib import LCV_EPI_GATE_RESIDUAL, LCV_EPI_SWIGLU
+    g = torch.Generator().manual_seed(2024)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    pick = lambda xs: xs[ri(0, len(xs) - 1)]
+    for case in range(40):
+        M = pick([ri(1, 3000), 256 * ri(1, 9) + pick([-1, 0, 1]), 128 * ri(1, 5) + pick([-1, 1])])
+        N = pick([256, 512, 768, 1024, 1280, 384])
+        K = pick([128, 192, 256, 320, 512, 1024])
+        K2 = pick([0, 0, 64, 128])
+        kind = pick(["plain", "nobias", "gate", "gate_short_frames", "gate_nomod", "swiglu"])
+        a = _randn(M, K, seed=100 + case).to(DEV); w = _randn(N, K, seed=200 + case, scale=0.05).to(DEV)
+        b = None if kind == "nobias" else _randn(N, seed=300 + case).to(DEV)
+        kw = {}
+        if K2:
+            kw.update(a2=_randn(M, K2, seed=400 + case).to(DEV), w2=_randn(N, K2, seed=500 + case, scale=0.05).to(DEV))
+        if kind in ("gate", "gate_short_frames"):
+            rpf = max(1, (M + 2) // 3) if kind == "gate" else max(1, min(M, 96))
+            T = (M + rpf - 1) // rpf
+            kw.update(epilogue=LCV_EPI_GATE_RESIDUAL, resid=_randn(M, N, seed=600 + case).to(DEV),
+                      mod=_randn(1, T, 3 * N, seed=700 + case, dtype=torch.float32).to(DEV), gate_idx=ri(0, 2), rows_per_frame=rpf)
+        if kind == "gate_nomod":
+            kw.update(epilogue=LCV_EPI_GATE_RESIDUAL, resid=_randn(M, N, seed=600 + case).to(DEV))
+        if kind == "swiglu":
+            if N % 64:
+                continue
+            kw.update(epilogue=LCV_EPI_SWIGLU)
+        monkeypatch.setenv("LCV_GEMM_TILE", "6")
+        ref = ops.gemm_nt(a, w, b, **kw)
+        monkeypatch.delenv("LCV_GEMM_TILE")
+        got = ops.gemm_nt(a, w, b, **kw)
+        assert torch.equal(got, ref), (case, M, N, K, K2, kind)
+        assert torch.equal(ops.gemm_nt(a, w, b, **kw), ref), (case, "repeat")
+
+
 @pytest.mark.parametrize("M,N,K,kind", [(12480, 4096, 4096, "plain"), (12480, 4096, 4096, "gate_residual"),
                                         (12480, 4096, 4096, "lora"), (12480, 4096, 11008, "f32out"), (12480 - 300, 4096 + 40, 1024, "plain")])
 def test_gemm_splitk_tail_matches_unsplit_and_fp32(M, N, K, kind, monkeypatch):
