@@ -63,6 +63,41 @@ def test_attention_backward(B, H, Nq, Nk):
     assert rel_l2(dk2, 2 * dk.float(), bound=1e-2) < 1e-2 and rel_l2(dv2, 2 * dv.float(), bound=1e-2) < 1e-2
 
 
+def test_attention_backward_fuzz_against_the_kernels_rounding_points():
+    """20 seeded random shapes through both families of backward kernels (general scale; unit scale = q in log2 units, the DiT's
+    self-attention) against `sdpa_backward_at_kernel_rounding` fed the forward's own O and lse: P and dS as bf16 MFMA operands with
+    the scale on the side of the rounding each family has it.  What is left is fp32 summation order."""
+    import math
+    from lcv_hip import ops
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+    from oracle import dit_oracle as orc
+    D = 128
+    g = torch.Generator().manual_seed(78)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    worst = 0.0
+    for case in range(20):
+        B, H = ri(1, 2), ri(1, 2)
+        Nq = [ri(1, 600), 32 * ri(1, 10) + ri(-1, 1)][case % 2]
+        Nk = [ri(1, 900), 128 * ri(1, 5) + ri(-1, 1), ri(1, 100)][(case // 2) % 3]
+        unit = case % 4 >= 2
+        q = _randn(B, Nq, H, D, seed=4000 + case); k = _randn(B, Nk, H, D, seed=5000 + case); v = _randn(B, Nk, H, D, seed=6000 + case)
+        do = _randn(B, Nq, H, D, seed=7000 + case)
+        scale = D ** -0.5
+        if unit:
+            q = (q.float() * (scale * math.log2(math.e))).to(BF16)
+            scale = math.log(2.0)
+        qd, kd, vd, dod = q.to(DEV), k.to(DEV), v.to(DEV), do.to(DEV)
+        o, lse = ops.attention(qd, kd, vd, scale, need_lse=True)
+        dq = torch.empty_like(qd); dk = torch.empty_like(kd); dv = torch.empty_like(vd)
+        ops.attention_bwd(qd, kd, vd, o, dod, lse, dq, dk, dv, scale)
+        rq, rk, rv = orc.sdpa_backward_at_kernel_rounding(*(t.permute(0, 2, 1, 3) for t in (q, k, v, do)), scale, scale_inside=not unit,
+                                                          o=o.cpu().permute(0, 2, 1, 3), lse=lse.cpu())
+        e = max(rel_l2(dq.permute(0, 2, 1, 3), rq), rel_l2(dk.permute(0, 2, 1, 3), rk), rel_l2(dv.permute(0, 2, 1, 3), rv))
+        worst = max(worst, e)
+        assert e < 5.0e-4, (case, B, H, Nq, Nk, unit, e)
+    print(f"attention backward fuzz: worst rel-L2 against the rounding-point checker {worst:.2e}")
+
+
 @pytest.mark.parametrize("B,H,Nq,Nk", [(1, 2, 300, 300), (2, 2, 70, 333), (1, 1, 256, 128), (2, 1, 129, 64), (1, 2, 33, 5)])
 def test_attention_backward_unit_scale_forms_on_the_product_layout(B, H, Nq, Nk, monkeypatch):
     """The second-form passes (`attn_bwd_dkv2_kernel`, `attn_bwd_dq2_kernel<4,2>` and `<8,4>`) that the self-attention of the DiT

@@ -181,6 +181,34 @@ def test_attention_64_rows_per_wave_kernel_is_the_default_and_equals_the_two_wav
     assert torch.allclose(lse.cpu(), torch.logsumexp(s, dim=-1), atol=3e-4, rtol=1e-5)
 
 
+def test_attention_fuzz_against_the_restatement_of_the_kernels_arithmetic():
+    """24 seeded random (batch, heads, queries, keys) through whichever forward kernel the launcher picks (general, two-wave, 64 rows
+    per wave; plain scale and q pre-scaled into log2 units), one key row spiked so the deferred rescale fires mid-stream, against
+    `sdpa_at_kernel_rounding`: only fp32 summation order separates them, so the bound is 20 x tighter than against fp32 softmax."""
+    ops, orc = _ops(), _orc()
+    D = 128
+    g = torch.Generator().manual_seed(77)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    worst = 0.0
+    for case in range(24):
+        B, H = ri(1, 2), ri(1, 3)
+        Nq = [ri(1, 700), 32 * ri(1, 12) + ri(-1, 1), 256 * ri(1, 2) + ri(-1, 1)][case % 3]
+        Nk = [ri(1, 1700), 64 * ri(1, 20) + ri(-1, 1), ri(513, 1400)][(case // 3) % 3]
+        unit = case % 2 == 1
+        q = _randn(B, Nq, H, D, seed=1000 + case); k = _randn(B, Nk, H, D, seed=2000 + case); v = _randn(B, Nk, H, D, seed=3000 + case)
+        k[0, (2 * Nk) // 3] *= 5.0
+        scale = D ** -0.5
+        if unit:
+            q = (q.float() * ops.log2_qscale(scale)).to(BF16)
+            scale = ops.LN2
+        o, _ = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), scale, need_lse=True)
+        ref = orc.sdpa_at_kernel_rounding(q.permute(0, 2, 1, 3), k.permute(0, 2, 1, 3), v.permute(0, 2, 1, 3), scale)
+        e = rel_l2(o.permute(0, 2, 1, 3), ref)
+        worst = max(worst, e)
+        assert e < 2.0e-4, (case, B, H, Nq, Nk, unit, e)
+    print(f"attention fuzz: worst rel-L2 against the restatement {worst:.2e}")
+
+
 def test_lse_merge_of_key_ranges_equals_the_one_call_attention():
     """Sequence parallelism's overlap path (`LCV_SP_OVERLAP=1`, lcv_hip/autograd_ops.py::_sp_attention_overlapped) attends the
     local keys while the gather is in flight and merges the partial results through their log-sum-exps.  The merge assumes
