@@ -388,6 +388,55 @@ def test_dit_lora_gradients_match_oracle_autograd(ncond, ckpt):
     assert max(errs) < 3e-2 and sorted(errs)[len(errs) // 2] < 1.5e-2      # measured 1.3e-2 / 8.4e-3 (round 2)
 
 
+def test_conditioned_loss_with_an_empty_conditioning_block():
+    """`tta_total_frames = tta_context_frames = 2` splits 0 / 1 / 0 - `cond_latents` is an EMPTY [B, 16, 0, h, w]
+    tensor, N_cond = 0 and the DiT runs with num_cond_latents = 0 (common.py:1388, 448-482; configs/exp3_train_frames_lora.yaml:29-33).
+    The conditioned loss must accept it: same sigma / noise draws as the oracle's restatement of the reference's input builder,
+    loss and LoRA gradients against oracle autograd."""
+    from oracle import dit_oracle as orc
+    from oracle import tta_oracle as T
+    from tta.lora import inject_lora_into_dit, get_lora_parameters
+    from tta.flow_matching import compute_flow_matching_loss_conditioned
+    m, cfg, P = _small_dit()
+    for p_ in m.parameters():
+        p_.requires_grad = False
+    mods = inject_lora_into_dit(m, rank=4, alpha=8.0, target_modules=["qkv", "proj"])
+    g = torch.Generator().manual_seed(9)
+    with torch.no_grad():
+        for lm in mods:
+            lm.lora_down.weight.copy_((torch.randn(lm.lora_down.weight.shape, generator=g) * 0.05).to(BF16))
+            lm.lora_up.weight.copy_((torch.randn(lm.lora_up.weight.shape, generator=g) * 0.05).to(BF16))
+    m.train()
+    B, H, W, L = 1, 8, 8, 16
+    cond = torch.zeros(B, 16, 0, H, W)
+    target = _randn(B, 16, 1, H, W, seed=41, dtype=torch.float32)
+    y = _randn(B, 1, L, 64, seed=42); mask = torch.zeros(B, L, dtype=torch.int64); mask[:, :9] = 1
+    torch.manual_seed(123)
+    loss = compute_flow_matching_loss_conditioned(m, cond.to(DEV), target.to(DEV), y.to(DEV), mask.to(DEV), device=DEV)
+    loss.backward()
+    # the same draws (the loss draws sigma with torch.rand and the noise with torch.randn_like on the device, in that order)
+    torch.manual_seed(123)
+    sigma = torch.rand(B, device=DEV, dtype=torch.float32) * (1.0 - 0.001) + 0.001
+    eps = torch.randn_like(target.to(DEV))
+    hs, ts, n_cond = T.build_conditioned_inputs(cond, target, sigma.cpu(), eps.cpu(), patch_t=1)
+    assert n_cond == 0 and hs.shape == (B, 16, 1, H, W)
+    names = T.lora_target_names(cfg["depth"], ("qkv", "proj"))      # injection order of the reference (run_lora_tta.py:286-359)
+    assert len(names) == len(mods)
+    P2 = {k: v.float() for k, v in P.items()}
+    leaves = []
+    for n, lm in zip(names, mods):
+        A_ = lm.lora_down.weight.detach().float().cpu().requires_grad_(True)
+        B_ = lm.lora_up.weight.detach().float().cpu().requires_grad_(True)
+        P2[n + ".weight"] = P2[n + ".weight"] + lm.scaling * (B_ @ A_)
+        leaves += [A_, B_]
+    ref = orc.dit_forward(P2, cfg, hs, ts, y, mask, 0, bf16=False)
+    ref_loss = T.conditioned_loss(ref, eps.cpu().float(), target.float(), 0)
+    ref_loss.backward()
+    assert abs(loss.item() - ref_loss.item()) < 2e-2 * abs(ref_loss.item()), (loss.item(), ref_loss.item())
+    errs = [rel_l2(p_.grad, l.grad) for p_, l in zip(get_lora_parameters(mods), leaves)]
+    assert max(errs) < 3e-2 and sorted(errs)[len(errs) // 2] < 1.5e-2, errs
+
+
 def test_inner_loop_matches_reference_run():
     """finetune_lora_on_conditioning (fused LoRA + fused clip/AdamW) against the losses and final adapter weights the
     reference's own loop produced on the toy DiT of tests/golden/make_golden.py (same injected sigma / eps)."""
