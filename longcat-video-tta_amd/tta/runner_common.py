@@ -102,12 +102,32 @@ def list_eval_entries(args, dit):
         n = int(d.split(":")[1]) if ":" in d else 4
         return [{"kind": "synthetic", "name": f"synthetic_{i:04d}", "path": f"synthetic://{i}", "seed": 1000 + i}
                 for i in range(min(n, args.max_videos))]
+    # WHICH clips and in WHICH order: the reference's own sampler (tta/datasets.py mirrors load_ucf101_video_list, the one every
+    # runner calls: run_lora_tta.py:911-913 - RandomState(seed), stratified by class) over the video files / metadata.csv of the
+    # data directory, so that a run here and a run of the reference over the same --data-dir --max-videos --seed adapt the same clips
+    from .datasets import load_ucf101_video_list
     lat = Path(d) / "latents"
+    try:
+        picked = load_ucf101_video_list(d, max_videos=args.max_videos, seed=getattr(args, "seed", 42), validate_decodable=not lat.is_dir())
+    except FileNotFoundError:
+        picked = None
     if lat.is_dir():
-        files = sorted(lat.glob("*.pt"))[: args.max_videos]
-        return [{"kind": "latents", "name": f.stem, "path": str(f)} for f in files]
-    vids = sorted(p for p in Path(d).rglob("*") if p.suffix.lower() in (".mp4", ".avi", ".mkv"))[: args.max_videos]
-    return [{"kind": "video", "name": v.stem, "path": str(v)} for v in vids]
+        if picked is None:      # pre-encoded clips only, no video files beside them: nothing for the sampler to order
+            files = sorted(lat.glob("*.pt"))[: args.max_videos]
+            return [{"kind": "latents", "name": f.stem, "path": str(f)} for f in files]
+        out, missing = [], []
+        for e in picked:
+            f = lat / (Path(e["video_path"]).stem + ".pt")
+            (out if f.exists() else missing).append({"kind": "latents", "name": f.stem, "path": str(f), "caption": e["caption"],
+                                                      "class_name": e["class_name"]})
+        if missing:
+            print(f"  {len(missing)} selected video(s) have no pre-encoded file under {lat} and are skipped: "
+                  + ", ".join(m["name"] for m in missing[:5]))
+        return out
+    if picked is None:
+        raise FileNotFoundError(f"No video files found in {d}")
+    return [{"kind": "video", "name": Path(e["video_path"]).stem, "path": e["video_path"], "caption": e["caption"],
+             "class_name": e["class_name"]} for e in picked]
 
 
 def load_entry(entry, args, dit, device, total_frames=None):
