@@ -68,7 +68,7 @@ def main(argv=None):
     for idx in dp.shard_indices(len(entries), rank, world):
         e = entries[idx]
         try:
-            blob = R.load_entry(e, args, dit, device, total_frames=args.num_cond_frames)
+            blob = R.load_entry(e, args, dit, device, total_frames=args.num_cond_frames, pipe=pipe)
             out, dt = R.generate_continuation(pipe, blob, args, idx, device, num_frames=num_frames, entry=e)
             row = {"idx": idx, "index": idx, "filename": e["name"], "caption": blob.get("caption", ""), "psnr": None,
                    "ssim": None, "lpips": None, "resolution": args.resolution, "inference_time_s": round(dt, 2)}

@@ -104,7 +104,7 @@ def main(argv=None):
         try:
             torch.manual_seed(dp.seed_for_video(args.seed, idx))
             reset_dit_weights(dit, base_state)                                          # :640 per-video reset
-            blob = R.load_entry(e, args, dit, device)
+            blob = R.load_entry(e, args, dit, device, pipe=pipe)
             cond, train, val = split_tta_latents(blob["latents"], n_ctx_lat, args.es_holdout_fraction)
             cond, train, variants = R.train_latents_variants_for(args, pipe, blob, e, cond, train, device)   # --aug-enabled (:699-722)
             pe, pm = blob["prompt_embeds"], blob["prompt_mask"]

@@ -176,7 +176,7 @@ def main(argv=None):
         e = entries[idx]
         try:
             torch.manual_seed(dp.seed_for_video(args.seed, idx))
-            blob = load_entry(e, args, dit, device)
+            blob = load_entry(e, args, dit, device, pipe=pipe)
             cond, train, val = split_tta_latents(blob["latents"], n_ctx_lat, args.es_holdout_fraction)
             n_tok = (cond.shape[2] + train.shape[2]) * (cond.shape[3] // 2) * (cond.shape[4] // 2)
             choose_gradient_checkpointing(dit, n_tok)

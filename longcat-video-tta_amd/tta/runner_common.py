@@ -130,7 +130,7 @@ def list_eval_entries(args, dit):
              "class_name": e["class_name"]} for e in picked]
 
 
-def load_entry(entry, args, dit, device, total_frames=None):
+def load_entry(entry, args, dit, device, total_frames=None, pipe=None):
     h, w = {"480p": (60, 104), "720p": (90, 160)}[args.resolution]
     if entry["kind"] == "synthetic":
         T = _estimate_latent_len(total_frames if total_frames is not None else args.tta_total_frames)
@@ -146,8 +146,11 @@ def load_entry(entry, args, dit, device, total_frames=None):
         blob.setdefault("caption", "")
         blob["latents"] = blob["latents"].to(torch.bfloat16)     # the TTA loss works on bf16 latents (common.py:463-466)
         return blob
-    raise NotImplementedError("raw-video input needs the PyAV decode + UMT5 rows that precede the hot path "
-                              "(SURVEY §8(f)); pre-encode to <data-dir>/latents/*.pt")
+    # a raw video file: PyAV decode of the reference's frame windows, VAE encode, UMT5 prompt encode (tta/video_io.py)
+    from .video_io import prepare_video_entry
+    if pipe is None:
+        raise RuntimeError("load_entry: a raw-video entry needs the pipeline (vae, tokenizer, text_encoder): pass pipe=")
+    return prepare_video_entry(entry, args, pipe, device, total_frames)
 
 
 def train_latents_variants_for(args, pipe, blob, entry, cond, train, device):
@@ -324,7 +327,7 @@ def run_delta_method(args, method: str, make_wrapper: Callable, optimize_fn: Cal
         wrapper = None
         try:
             torch.manual_seed(dp.seed_for_video(args.seed, idx))
-            blob = load_entry(e, args, dit, device)
+            blob = load_entry(e, args, dit, device, pipe=pipe)
             cond, train, val = split_tta_latents(blob["latents"], n_ctx_lat, args.es_holdout_fraction)
             n_tok = (cond.shape[2] + train.shape[2]) * (cond.shape[3] // 2) * (cond.shape[4] // 2)
             choose_gradient_checkpointing(dit, n_tok)
