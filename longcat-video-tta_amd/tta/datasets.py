@@ -152,3 +152,69 @@ def load_panda70m_video_list(data_dir: str, meta_path: Optional[str] = None, max
     rng = np.random.RandomState(seed)
     rng.shuffle(entries)
     return entries[:max_videos]
+
+
+# ---- caption quality guard and caption override (common.py:1019-1157; every runner calls both right after the listing:
+# run_lora_tta.py:914-925).  A listing whose captions are mostly empty, mostly identical or dominated by a placeholder is a
+# mis-joined metadata file, and adapting 100 videos to "a video clip" is an expensive way to find out.
+GENERIC_CAPTIONS = {"", "video", "videos", "a video", "a video clip", "video clip", "unknown", "none", "nan"}
+
+
+def analyze_caption_quality(video_entries: List[Dict[str, Any]], top_k: int = 5) -> Dict[str, Any]:
+    total = len(video_entries)
+    nonempty = [c for c in (str(v.get("caption", "")).strip() for v in video_entries) if c]
+    counts = Counter(c.lower() for c in nonempty)
+    n = len(nonempty)
+    top = counts.most_common(max(int(top_k), 1))
+    top1_caption, top1_count = top[0] if top else ("", 0)
+    return {"total": total, "nonempty_count": n, "nonempty_ratio": (n / total) if total else 0.0, "unique_count": len(counts),
+            "unique_ratio": (len(counts) / n) if n else 0.0, "top1_caption": top1_caption, "top1_count": top1_count,
+            "top1_ratio": (top1_count / n) if n else 0.0, "avg_caption_len": float(np.mean([len(c) for c in nonempty])) if nonempty else 0.0,
+            "top_captions": top}
+
+
+def validate_caption_quality(video_entries: List[Dict[str, Any]], *, mode: str = "fail", min_nonempty_ratio: float = 0.95,
+                             min_unique_ratio: float = 0.10, max_top1_ratio: float = 0.50, max_generic_top1_ratio: float = 0.20,
+                             top_k: int = 5, context: str = "") -> Dict[str, Any]:
+    mode = (mode or "fail").lower()
+    if mode not in {"fail", "warn", "off"}:
+        raise ValueError(f"Invalid caption guard mode: {mode}")
+    st = analyze_caption_quality(video_entries, top_k=top_k)
+    prefix = f"[caption_guard:{context}]" if context else "[caption_guard]"
+    print(f"{prefix} total={st['total']} nonempty_ratio={st['nonempty_ratio']:.4f} unique_ratio={st['unique_ratio']:.4f} "
+          f"top1_ratio={st['top1_ratio']:.4f} avg_len={st['avg_caption_len']:.1f}")
+    if st["top_captions"]:
+        print(f"{prefix} top captions:")
+        for cap, count in st["top_captions"]:
+            print(f"  - {count:4d} | {cap[:180]}")
+    if mode == "off" or st["total"] < 20:          # small listings are never judged
+        return st
+    reasons = []
+    if st["nonempty_ratio"] < float(min_nonempty_ratio):
+        reasons.append(f"nonempty_ratio={st['nonempty_ratio']:.4f} < {float(min_nonempty_ratio):.4f}")
+    if st["unique_ratio"] < float(min_unique_ratio):
+        reasons.append(f"unique_ratio={st['unique_ratio']:.4f} < {float(min_unique_ratio):.4f}")
+    if st["top1_ratio"] > float(max_top1_ratio):
+        reasons.append(f"top1_ratio={st['top1_ratio']:.4f} > {float(max_top1_ratio):.4f}")
+    if st["top1_caption"] in GENERIC_CAPTIONS and st["top1_ratio"] > float(max_generic_top1_ratio):
+        reasons.append(f"generic top caption dominates ('{st['top1_caption']}' ratio={st['top1_ratio']:.4f} > "
+                       f"{float(max_generic_top1_ratio):.4f})")
+    if reasons:
+        msg = f"{prefix} suspicious captions detected: " + "; ".join(reasons)
+        if mode == "warn":
+            print(f"WARNING: {msg}")
+        else:
+            raise RuntimeError(msg)
+    return st
+
+
+def apply_fixed_caption(video_entries: List[Dict[str, Any]], fixed_caption: Optional[str], *, context: str = "eval") -> List[Dict[str, Any]]:
+    if fixed_caption is None:
+        return video_entries
+    cap = str(fixed_caption).strip()
+    if len(cap) >= 2 and cap[0] == cap[-1] and cap[0] in ("'", '"'):      # a shell-quoted literal that arrived with its quotes
+        cap = cap[1:-1]
+    for row in video_entries:
+        row["caption"] = cap
+    print(f"[caption_override:{context}] applied fixed caption to {len(video_entries)} videos: {cap!r}")
+    return video_entries

@@ -97,6 +97,23 @@ def load_components(args, device):
 
 
 def list_eval_entries(args, dit):
+    """The clips of this run, in order - then, as every reference runner does right after its listing (run_lora_tta.py:911-925):
+    `--fixed-caption` applied and the caption guard run over them (mode `fail` raises on a listing whose captions are mostly empty,
+    identical or a placeholder; listings under 20 clips are never judged)."""
+    from .datasets import apply_fixed_caption, validate_caption_quality
+    entries = _list_entries(args, dit)
+    if entries and entries[0]["kind"] != "synthetic" and any("caption" in e for e in entries):
+        entries = apply_fixed_caption(entries, getattr(args, "fixed_caption", None), context="eval")
+        validate_caption_quality(entries, mode=getattr(args, "caption_guard_mode", "fail"),
+                                 min_nonempty_ratio=getattr(args, "caption_guard_min_nonempty_ratio", 0.95),
+                                 min_unique_ratio=getattr(args, "caption_guard_min_unique_ratio", 0.10),
+                                 max_top1_ratio=getattr(args, "caption_guard_max_top1_ratio", 0.50),
+                                 max_generic_top1_ratio=getattr(args, "caption_guard_max_generic_top1_ratio", 0.20),
+                                 top_k=getattr(args, "caption_guard_topk", 5), context="eval")
+    return entries
+
+
+def _list_entries(args, dit):
     d = args.data_dir
     if d.startswith("synthetic"):
         n = int(d.split(":")[1]) if ":" in d else 4
@@ -145,6 +162,15 @@ def load_entry(entry, args, dit, device, total_frames=None, pipe=None):
         blob = torch.load(entry["path"], map_location=device)
         blob.setdefault("caption", "")
         blob["latents"] = blob["latents"].to(torch.bfloat16)     # the TTA loss works on bf16 latents (common.py:463-466)
+        fixed = getattr(args, "fixed_caption", None)
+        if fixed is not None and entry.get("caption") is not None and entry["caption"] != blob["caption"]:
+            # --fixed-caption over a pre-encoded clip: its stored embeddings belong to another caption
+            if pipe is None or getattr(pipe, "tokenizer", None) is None or getattr(pipe, "text_encoder", None) is None:
+                raise RuntimeError(f"--fixed-caption {entry['caption']!r}: {entry['path']} was pre-encoded with the caption "
+                                   f"{blob['caption']!r} and this run has no tokenizer / text encoder to encode the override")
+            from tta.common import encode_prompt
+            blob["prompt_embeds"], blob["prompt_mask"] = encode_prompt(pipe.tokenizer, pipe.text_encoder, entry["caption"], device=device)
+            blob["caption"] = entry["caption"]
         return blob
     # a raw video file: PyAV decode of the reference's frame windows, VAE encode, UMT5 prompt encode (tta/video_io.py)
     from .video_io import prepare_video_entry

@@ -74,3 +74,54 @@ def test_runner_listing_follows_the_sampler_and_maps_to_pre_encoded_clips():
             (only / "latents" / f"{n}.pt").write_bytes(b"")
         args2 = types.SimpleNamespace(data_dir=str(only), max_videos=2, seed=42)
         assert [e["name"] for e in R.list_eval_entries(args2, None)] == ["a", "b"]
+
+
+CAP = json.loads((ROOT / "tests" / "golden" / "caption_guard.json").read_text())
+
+
+@pytest.mark.parametrize("i", range(len(CAP["cases"])))
+def test_caption_guard_equals_the_reference(i):
+    """Statistics, thresholds and the raised message of `validate_caption_quality` (common.py:1035-1137) on seeded caption lists."""
+    c = CAP["cases"][i]
+    entries = [dict(e) for e in CAP["lists"][c["list"]]]
+    if "raises" in c:
+        with pytest.raises(RuntimeError) as ei:
+            DS.validate_caption_quality(entries, **c["kw"])
+        assert str(ei.value) == c["raises"]
+    else:
+        st = DS.validate_caption_quality(entries, **c["kw"])
+        want = dict(c["stats"])
+        assert [list(t) for t in st.pop("top_captions")] == want.pop("top_captions")
+        assert st == want
+
+
+def test_fixed_caption_override_and_generic_list_equal_the_reference():
+    for c in CAP["fixed"]:
+        rows = [{"caption": "one"}, {"caption": "two", "k": 1}]
+        assert [r["caption"] for r in DS.apply_fixed_caption(rows, c["fixed_caption"])] == c["captions"]
+    assert sorted(DS.GENERIC_CAPTIONS) == CAP["generic"]
+    with pytest.raises(ValueError, match="Invalid caption guard mode"):
+        DS.validate_caption_quality([], mode="strict")
+
+
+def test_runner_listing_applies_the_override_and_runs_the_guard():
+    import types
+    from tta import runner_common as R
+    with tempfile.TemporaryDirectory() as td:
+        root = Path(td) / "data"
+        (root / "videos").mkdir(parents=True)
+        rows = [[f"v{i:02d}.mp4", "A video clip" if i < 20 else f"a person does thing {i}", f"c{i % 3}"] for i in range(30)]
+        for r in rows:
+            (root / "videos" / r[0]).write_bytes(b"")
+        with open(root / "metadata.csv", "w", newline="") as f:
+            w = csv.writer(f); w.writerow(["filename", "caption", "category"]); w.writerows(rows)
+        (root / "latents").mkdir()
+        for r in rows:
+            (root / "latents" / (Path(r[0]).stem + ".pt")).write_bytes(b"")
+        base = dict(data_dir=str(root), max_videos=30, seed=42)
+        with pytest.raises(RuntimeError, match=r"\[caption_guard:eval\] suspicious captions detected: .*generic top caption dominates"):
+            R.list_eval_entries(types.SimpleNamespace(**base), None)                         # mode defaults to fail
+        got = R.list_eval_entries(types.SimpleNamespace(caption_guard_mode="warn", **base), None)
+        assert len(got) == 30
+        got = R.list_eval_entries(types.SimpleNamespace(fixed_caption='"a juggler"', caption_guard_mode="off", **base), None)
+        assert {e["caption"] for e in got} == {"a juggler"}
