@@ -49,6 +49,21 @@ def _resolve(data_dir: Path, fname: str) -> Optional[Path]:
     return None
 
 
+def _rows_of_metadata(root: Path, meta: Path, class_of, errors=None) -> List[Dict]:
+    """Entries of a metadata file whose video exists (under `videos/` or beside the file); [] when there is no such file."""
+    if not meta.exists():
+        return []
+    kw = {"encoding": "utf-8", "errors": errors} if errors else {}
+    out = []
+    with open(meta, "r", **kw) as f:
+        for row in csv.DictReader(f):
+            vp = _resolve(root, row.get("filename", row.get("video_path", "")))
+            if vp is not None:
+                out.append({"video_path": str(vp), "caption": normalize_caption(row.get("caption", row.get("text", ""))),
+                            "class_name": class_of(row)})
+    return out
+
+
 def _keep_decodable(entries: List[Dict], what: str) -> List[Dict]:
     try:
         import av
@@ -79,18 +94,10 @@ def _keep_decodable(entries: List[Dict], what: str) -> List[Dict]:
 def load_ucf101_video_list(data_dir: str, max_videos: int = 100, seed: int = 42, stratified: bool = True,
                            validate_decodable: bool = False) -> List[Dict]:
     root = Path(data_dir)
-    entries: List[Dict] = []
     meta = root / "metadata.csv"
-    if meta.exists():
-        with open(meta, "r", encoding="utf-8", errors="replace") as f:
-            for row in csv.DictReader(f):
-                vp = _resolve(root, row.get("filename", row.get("video_path", "")))
-                if vp is None:
-                    continue
-                entries.append({"video_path": str(vp), "caption": normalize_caption(row.get("caption", row.get("text", ""))),
-                                "class_name": row.get("category", row.get("class_name", "unknown"))})
-        if entries:
-            print(f"  Loaded {len(entries)} videos from {meta}")
+    entries = _rows_of_metadata(root, meta, lambda row: row.get("category", row.get("class_name", "unknown")), errors="replace")
+    if entries:
+        print(f"  Loaded {len(entries)} videos from {meta}")
     if not entries:
         for pattern in ("*.mp4", "*.avi"):
             for vp in sorted(root.rglob(pattern)):
@@ -136,17 +143,10 @@ def load_ucf101_video_list(data_dir: str, max_videos: int = 100, seed: int = 42,
 def load_panda70m_video_list(data_dir: str, meta_path: Optional[str] = None, max_videos: int = 100, seed: int = 42,
                              validate_decodable: bool = False) -> List[Dict]:
     root = Path(data_dir)
-    entries: List[Dict] = []
     if meta_path and Path(meta_path).exists():
-        with open(meta_path, "r") as f:
-            for row in csv.DictReader(f):
-                vp = _resolve(root, row.get("filename", row.get("video_path", "")))
-                if vp is not None:
-                    entries.append({"video_path": str(vp), "caption": normalize_caption(row.get("caption", row.get("text", ""))),
-                                    "class_name": "panda70m"})
+        entries = _rows_of_metadata(root, Path(meta_path), lambda row: "panda70m")
     else:
-        for vp in sorted(root.rglob("*.mp4")):
-            entries.append({"video_path": str(vp), "caption": "A video clip", "class_name": "panda70m"})
+        entries = [{"video_path": str(vp), "caption": "A video clip", "class_name": "panda70m"} for vp in sorted(root.rglob("*.mp4"))]
     if validate_decodable:
         entries = _keep_decodable(entries, "Panda")
     rng = np.random.RandomState(seed)
@@ -189,11 +189,8 @@ def validate_caption_quality(video_entries: List[Dict[str, Any]], *, mode: str =
             print(f"  - {count:4d} | {cap[:180]}")
     if mode == "off" or st["total"] < 20:          # small listings are never judged
         return st
-    reasons = []
-    if st["nonempty_ratio"] < float(min_nonempty_ratio):
-        reasons.append(f"nonempty_ratio={st['nonempty_ratio']:.4f} < {float(min_nonempty_ratio):.4f}")
-    if st["unique_ratio"] < float(min_unique_ratio):
-        reasons.append(f"unique_ratio={st['unique_ratio']:.4f} < {float(min_unique_ratio):.4f}")
+    floors = (("nonempty_ratio", float(min_nonempty_ratio)), ("unique_ratio", float(min_unique_ratio)))
+    reasons = [f"{k}={st[k]:.4f} < {lim:.4f}" for k, lim in floors if st[k] < lim]
     if st["top1_ratio"] > float(max_top1_ratio):
         reasons.append(f"top1_ratio={st['top1_ratio']:.4f} > {float(max_top1_ratio):.4f}")
     if st["top1_caption"] in GENERIC_CAPTIONS and st["top1_ratio"] > float(max_generic_top1_ratio):
